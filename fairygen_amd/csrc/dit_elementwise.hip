@@ -1,0 +1,354 @@
+// DiT token-side kernels: LayerNorm+modulate, LayerNorm affine, gate-residual (+ fused next norm),
+// RMSNorm(+RoPE), activations, CFG+Euler.  All are HBM-bound: one wave owns one token row, keeps it in
+// registers (C <= 4096 -> <= 8 x 16-byte vectors per lane), reduces with wave shuffles (no LDS, no
+// barrier) and touches every byte exactly once with 16-byte coalesced accesses.
+// Rounding points mirror the reference's bf16 tensor arithmetic op by op (see include/fairygen_hip.h).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxVec = 8;            // 8 lanes-vectors * 64 lanes * 8 elems = 4096 channels max
+constexpr int kRowsPerBlock = 4;      // 4 waves per 256-thread workgroup
+
+struct Row {
+    float v[kMaxVec][8];
+};
+
+__device__ __forceinline__ void load_row(const bf16* p, int C, int lane, Row& r) {
+    const int nvec = C >> 3;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            bf16x8 t = *reinterpret_cast<const bf16x8*>(p + (int64_t)vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.v[i][j] = (float)t[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st8(bf16* p, const float* f) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (bf16)f[j];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// mean / rstd of a row held in registers (two-pass, fp32).
+__device__ __forceinline__ void row_moments(const Row& r, int C, int lane, float eps, float& mean, float& rstd) {
+    const int nvec = C >> 3;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += r.v[i][j];
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        if (lane + i * 64 < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = r.v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)C;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ int64_t mod_row(int64_t row, int64_t mod_rows, int64_t first_rows) {
+    return mod_rows == 1 ? 0 : (mod_rows == 2 ? (row < first_rows ? 0 : 1) : row);
+}
+
+// norm_out = modulate(LN(row)) or LN(row)*w+b, written from registers.
+template <int MODE>
+__device__ __forceinline__ void norm_store(const Row& r, int C, int lane, float eps, const bf16* p0, const bf16* p1,
+                                           bf16* out) {
+    const int nvec = C >> 3;
+    float mean, rstd;
+    row_moments(r, C, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const bf16x8 a = ld8(p0 + (int64_t)vi * 8);
+            const bf16x8 b = ld8(p1 + (int64_t)vi * 8);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = (r.v[i][j] - mean) * rstd;
+                if (MODE == 0) {  // p0 = shift, p1 = scale
+                    const float y = rbf(n);
+                    const float s1 = rbf(1.0f + (float)b[j]);
+                    o[j] = rbf(y * s1) + (float)a[j];
+                } else {          // p0 = weight, p1 = bias
+                    o[j] = n * (float)a[j] + (float)b[j];
+                }
+            }
+            st8(out + (int64_t)vi * 8, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shift,
+                                                          const bf16* __restrict__ scale, bf16* __restrict__ out,
+                                                          int64_t rows, int C, float eps, int64_t mod_rows,
+                                                          int64_t first_rows, int64_t mod_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row r;
+    load_row(x + row * C, C, lane, r);
+    const int64_t m = mod_row(row, mod_rows, first_rows);
+    norm_store<0>(r, C, lane, eps, shift + m * mod_ld, scale + m * mod_ld, out + row * C);
+}
+
+__global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                        const bf16* __restrict__ b, bf16* __restrict__ out,
+                                                        int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row r;
+    load_row(x + row * C, C, lane, r);
+    norm_store<1>(r, C, lane, eps, w, b, out + row * C);
+}
+
+// x_out = x + gate*y ; optional fused norm of x_out.  MODE: -1 none, 0 modulate, 1 affine.
+template <int MODE>
+__global__ __launch_bounds__(256) void residual_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y,
+                                                       const bf16* __restrict__ gate, bf16* __restrict__ x_out,
+                                                       const bf16* __restrict__ p0, const bf16* __restrict__ p1,
+                                                       bf16* __restrict__ norm_out, int64_t rows, int C, float eps,
+                                                       int64_t mod_rows, int64_t first_rows, int64_t mod_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    const int64_t m = mod_row(row, mod_rows, first_rows);
+    Row r;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const bf16x8 xv = ld8(x + row * C + (int64_t)vi * 8);
+            const bf16x8 yv = ld8(y + row * C + (int64_t)vi * 8);
+            if (gate != nullptr) {
+                const bf16x8 gv = ld8(gate + m * mod_ld + (int64_t)vi * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r.v[i][j] = rbf((float)xv[j] + rbf((float)gv[j] * (float)yv[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r.v[i][j] = rbf((float)xv[j] + (float)yv[j]);
+            }
+            st8(x_out + row * C + (int64_t)vi * 8, r.v[i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+        }
+    }
+    if (MODE == 0) norm_store<0>(r, C, lane, eps, p0 + m * mod_ld, p1 + m * mod_ld, norm_out + row * C);
+    if (MODE == 1) norm_store<1>(r, C, lane, eps, p0, p1, norm_out + row * C);
+}
+
+// RMSNorm over the whole row, * weight, then RoPE on adjacent pairs in fp64 (as the reference does).
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
+                                                           const bf16* __restrict__ w, const double* __restrict__ ct,
+                                                           const double* __restrict__ st, bf16* __restrict__ out,
+                                                           int64_t rows, int C, int head_dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    Row r;
+    load_row(x + row * ldx, C, lane, r);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q += r.v[i][j] * r.v[i][j];
+    const float ms = wave_sum(q) / (float)C;
+    const float rinv = 1.0f / sqrtf(ms + eps);
+    const int half = head_dim >> 1;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const bf16x8 wv = ld8(w + (int64_t)vi * 8);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(r.v[i][j] * rinv) * (float)wv[j]);
+            if (ct != nullptr) {
+                const int d0 = (vi * 8) % head_dim;          // channel within the head, multiple of 8
+                const double* cp = ct + row * half + (d0 >> 1);
+                const double* sp = st + row * half + (d0 >> 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double a = (double)o[2 * j], b = (double)o[2 * j + 1];
+                    const double c = cp[j], s = sp[j];
+                    o[2 * j] = (float)(bf16)(a * c - b * s);
+                    o[2 * j + 1] = (float)(bf16)(a * s + b * c);
+                }
+            }
+            st8(out + row * C + (int64_t)vi * 8, o);
+        }
+    }
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+    const float u = kBeta * (x + kKappa * x * x * x);
+    // tanh(u) = 1 - 2/(1+exp(2u)); clamp keeps exp finite.
+    const float e = __expf(2.0f * fminf(u, 15.0f));
+    const float t = 1.0f - 2.0f / (1.0f + e);
+    return 0.5f * x * (1.0f + t);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void act_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = ld8(x + i * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = KIND == 0 ? silu_f((float)v[j]) : gelu_tanh_f((float)v[j]);
+        st8(out + i * 8, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const bf16* __restrict__ lat, const bf16* __restrict__ posi,
+                                                        const bf16* __restrict__ nega, bf16* __restrict__ out,
+                                                        int64_t n, float cfg, float dsigma) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = (float)posi[i];
+        float pred = p;
+        if (nega != nullptr) {
+            const float ng = (float)nega[i];
+            pred = rbf(ng + rbf(cfg * rbf(p - ng)));
+        }
+        out[i] = (bf16)((float)lat[i] + rbf(pred * dsigma));
+    }
+}
+
+inline int check_rows(const char* fn, int64_t rows, int C, int64_t mod_rows, int64_t first_rows) {
+    FG_CHECK_ARG(rows >= 0 && C > 0 && (C % 8) == 0 && C <= kMaxVec * 512, "%s: need C %% 8 == 0 and C <= %d (got rows=%lld C=%d)",
+                 fn, kMaxVec * 512, (long long)rows, C);
+    FG_CHECK_ARG(mod_rows == 1 || mod_rows == 2 || mod_rows == rows, "%s: mod_rows must be 1, 2 or rows (got %lld)", fn,
+                 (long long)mod_rows);
+    FG_CHECK_ARG(first_rows >= 0 && first_rows <= rows, "%s: first_rows out of range", fn);
+    return FG_OK;
+}
+
+inline dim3 row_grid(int64_t rows) { return dim3((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)); }
+
+}  // namespace
+
+extern "C" {
+
+int fg_ln_modulate_bf16(const void* x, const void* shift, const void* scale, void* out, int64_t rows, int C, float eps,
+                        int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream) {
+    if (int e = check_rows("fg_ln_modulate_bf16", rows, C, mod_rows, first_rows)) return e;
+    FG_CHECK_ARG(x && shift && scale && out, "fg_ln_modulate_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(shift) && FG_ALIGNED16(scale) && FG_ALIGNED16(out) && mod_ld % 8 == 0,
+                 "fg_ln_modulate_bf16: pointers / mod_ld must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(ln_modulate_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)shift, (const bf16*)scale, (bf16*)out, rows, C, eps, mod_rows, first_rows, mod_ld);
+    return fg_launch_status("fg_ln_modulate_bf16");
+}
+
+int fg_ln_affine_bf16(const void* x, const void* w, const void* b, void* out, int64_t rows, int C, float eps,
+                      fg_stream_t stream) {
+    if (int e = check_rows("fg_ln_affine_bf16", rows, C, 1, 0)) return e;
+    FG_CHECK_ARG(x && w && b && out, "fg_ln_affine_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(w) && FG_ALIGNED16(b) && FG_ALIGNED16(out),
+                 "fg_ln_affine_bf16: pointers must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(ln_affine_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)w,
+                       (const bf16*)b, (bf16*)out, rows, C, eps);
+    return fg_launch_status("fg_ln_affine_bf16");
+}
+
+int fg_gate_residual_bf16(const void* x, const void* y, const void* gate, void* out, int64_t rows, int C, int64_t mod_rows,
+                          int64_t first_rows, int64_t mod_ld, fg_stream_t stream) {
+    if (int e = check_rows("fg_gate_residual_bf16", rows, C, gate ? mod_rows : 1, gate ? first_rows : 0)) return e;
+    FG_CHECK_ARG(x && y && out, "fg_gate_residual_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(y) && FG_ALIGNED16(gate) && FG_ALIGNED16(out) && mod_ld % 8 == 0,
+                 "fg_gate_residual_bf16: pointers / mod_ld must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(residual_kernel<-1>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)y, (const bf16*)gate, (bf16*)out, (const bf16*)nullptr, (const bf16*)nullptr,
+                       (bf16*)nullptr, rows, C, 0.f, gate ? mod_rows : 1, gate ? first_rows : 0, mod_ld);
+    return fg_launch_status("fg_gate_residual_bf16");
+}
+
+int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_out, const void* p0, const void* p1,
+                        void* norm_out, int mode, int64_t rows, int C, float eps, int64_t mod_rows, int64_t first_rows,
+                        int64_t mod_ld, fg_stream_t stream) {
+    FG_CHECK_ARG(mode == 0 || mode == 1, "fg_residual_ln_bf16: mode must be 0 (modulate) or 1 (affine)");
+    const bool need_mod = gate != nullptr || mode == 0;
+    if (int e = check_rows("fg_residual_ln_bf16", rows, C, need_mod ? mod_rows : 1, need_mod ? first_rows : 0)) return e;
+    FG_CHECK_ARG(x && y && x_out && p0 && p1 && norm_out, "fg_residual_ln_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(y) && FG_ALIGNED16(gate) && FG_ALIGNED16(x_out) && FG_ALIGNED16(p0) &&
+                     FG_ALIGNED16(p1) && FG_ALIGNED16(norm_out) && mod_ld % 8 == 0,
+                 "fg_residual_ln_bf16: pointers / mod_ld must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    if (!need_mod) { mod_rows = 1; first_rows = 0; }
+    if (mode == 0)
+        hipLaunchKernelGGL(residual_kernel<0>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)y, (const bf16*)gate, (bf16*)x_out, (const bf16*)p0, (const bf16*)p1,
+                           (bf16*)norm_out, rows, C, eps, mod_rows, first_rows, mod_ld);
+    else
+        hipLaunchKernelGGL(residual_kernel<1>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)y, (const bf16*)gate, (bf16*)x_out, (const bf16*)p0, (const bf16*)p1,
+                           (bf16*)norm_out, rows, C, eps, mod_rows, first_rows, mod_ld);
+    return fg_launch_status("fg_residual_ln_bf16");
+}
+
+int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight, const double* cos_tab, const double* sin_tab,
+                         void* out, int64_t rows, int C, int num_heads, float eps, fg_stream_t stream) {
+    if (int e = check_rows("fg_rmsnorm_rope_bf16", rows, C, 1, 0)) return e;
+    FG_CHECK_ARG(x && weight && out, "fg_rmsnorm_rope_bf16: null pointer");
+    FG_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "fg_rmsnorm_rope_bf16: pass both tables or neither");
+    FG_CHECK_ARG(num_heads > 0 && C % num_heads == 0 && (C / num_heads) % 8 == 0,
+                 "fg_rmsnorm_rope_bf16: head_dim must be a multiple of 8");
+    FG_CHECK_ARG(ldx >= C && ldx % 8 == 0 && FG_ALIGNED16(x) && FG_ALIGNED16(weight) && FG_ALIGNED16(out) &&
+                     FG_ALIGNED16(cos_tab) && FG_ALIGNED16(sin_tab),
+                 "fg_rmsnorm_rope_bf16: pointers / ldx must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps);
+    return fg_launch_status("fg_rmsnorm_rope_bf16");
+}
+
+int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t stream) {
+    FG_CHECK_ARG(x && out && n >= 0 && n % 8 == 0, "fg_act_bf16: n must be a multiple of 8");
+    FG_CHECK_ARG(kind == 0 || kind == 1, "fg_act_bf16: kind must be 0 (silu) or 1 (gelu_tanh)");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(out), "fg_act_bf16: pointers must be 16-byte aligned");
+    if (n == 0) return FG_OK;
+    const int64_t nvec = n / 8;
+    const unsigned grid = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    if (kind == 0)
+        hipLaunchKernelGGL(act_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, nvec);
+    else
+        hipLaunchKernelGGL(act_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, nvec);
+    return fg_launch_status("fg_act_bf16");
+}
+
+int fg_cfg_euler_bf16(const void* latents, const void* posi, const void* nega, void* out, int64_t n, float cfg_scale,
+                      float dsigma, fg_stream_t stream) {
+    FG_CHECK_ARG(latents && posi && out && n >= 0, "fg_cfg_euler_bf16: null pointer");
+    if (n == 0) return FG_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)latents,
+                       (const bf16*)posi, (const bf16*)nega, (bf16*)out, n, cfg_scale, dsigma);
+    return fg_launch_status("fg_cfg_euler_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// Causal 3-D convolution of the Wan2.2 VAE decoder as an implicit GEMM on bf16 MFMA (gfx950).
+//
+// Replaces CausalConv3d.forward (models/wan_video_vae.py:33-52) incl. its feature-cache concat, and the
+// nearest-exact-2x Upsample + Conv2d pair of Resample38 (:242-251), the channel->time interleave after
+// time_conv (:153-156) and the residual add of ResidualBlock (:301).
+//
+// Layout: activations channels-last (T,H,W,C) so that the reduction (tap, cin) is contiguous over cin;
+// weights pre-packed once to [tap][Cout_pad][Cin_pad] (cin contiguous) by fg_conv_pack_weight_bf16.
+// GEMM view: D[cout][pixel] = sum_{tap,cin} Wp[tap][cout][cin] * X[pixel shifted by tap][cin]
+//   (weights are the MFMA A operand, pixels the B operand: the accumulator then holds, per lane, ONE pixel
+//    and 4 consecutive couts per register group -> 8-byte channels-last stores, lane-local bias/residual).
+// Tile: 128 couts x 128 pixels x 64 cin per step, 4 waves (2x2), each 64x64 = 2x2 v_mfma_f32_32x32x16_bf16
+// accumulators; A/B tiles staged global->reg->LDS, double buffered, one barrier per step; LDS rows are 128 B
+// with the 16-B chunk index XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128.
+// Roofline: MFMA (≈4000 FLOP/B at 704x1280).
+#include "common.h"
+
+namespace {
+
+constexpr int kBMc = 128;   // couts per tile
+constexpr int kBNp = 128;   // pixels per tile
+constexpr int kBK = 64;     // cin per step
+constexpr int kTile = 128 * kBK * 2;   // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+struct ConvParams {
+    const bf16* x;
+    const bf16* prev;
+    const bf16* wp;
+    const bf16* bias;
+    const bf16* residual;
+    bf16* out;
+    int T, H, W, Hin, Win, Cin, Cout, kt, ks, cin_pad, cout_pad, upsample, interleave;
+    int64_t M;      // T*H*W output pixels
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * kTile];   // A0 A1 B0 B1
+    char* const a_lds = smem;               // weights tile
+    char* const b_lds = smem + 2 * kTile;   // pixel tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int n_ctiles = p.cout_pad / kBMc;
+    const int ctile = blockIdx.x % n_ctiles;
+    const int64_t ptile = blockIdx.x / n_ctiles;
+    const int c0 = ctile * kBMc;
+    const int64_t m0 = ptile * kBNp;
+
+    // ---- staging roles: thread moves rows (tid>>3)+32*i, chunk (tid&7) of both tiles
+    const int st_row = tid >> 3, st_chunk = tid & 7;
+    int pt[4], py[4], px[4];
+    bool pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + st_row + 32 * i;
+        pv[i] = m < p.M;
+        const int64_t mm = pv[i] ? m : 0;
+        px[i] = (int)(mm % p.W);
+        py[i] = (int)((mm / p.W) % p.H);
+        pt[i] = (int)(mm / ((int64_t)p.W * p.H));
+    }
+    const int pad = p.ks >> 1;
+    const int ksteps_per_tap = p.cin_pad / kBK;
+    const int ntaps = p.kt * p.ks * p.ks;
+    const int nsteps = ntaps * ksteps_per_tap;
+
+    u32x4 areg[4], breg[4];
+    auto stage_load = [&](int step) {
+        const int tap = step / ksteps_per_tap;
+        const int cin0 = (step - tap * ksteps_per_tap) * kBK + st_chunk * 8;
+        const int dt = tap / (p.ks * p.ks);
+        const int dy = (tap / p.ks) % p.ks;
+        const int dx = tap % p.ks;
+        const bf16* wbase = p.wp + ((int64_t)tap * p.cout_pad + c0) * p.cin_pad + cin0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            areg[i] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)(st_row + 32 * i) * p.cin_pad);
+            u32x4 val = {0u, 0u, 0u, 0u};
+            int yy = py[i] + dy - pad, xx = px[i] + dx - pad;
+            const int ft = pt[i] + dt - (p.kt - 1);
+            if (pv[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && cin0 < p.Cin) {
+                if (p.upsample) { yy >>= 1; xx >>= 1; }
+                const int64_t pix = (int64_t)yy * p.Win + xx;
+                const int64_t fsz = (int64_t)p.Hin * p.Win;
+                if (ft >= 0)
+                    val = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)ft * fsz + pix) * p.Cin + cin0);
+                else if (p.prev != nullptr)
+                    val = *reinterpret_cast<const u32x4*>(p.prev + ((int64_t)(ft + 2) * fsz + pix) * p.Cin + cin0);
+            }
+            breg[i] = val;
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = lds_off(st_row + 32 * i, st_chunk);
+            *reinterpret_cast<u32x4*>(a_lds + buf * kTile + off) = areg[i];
+            *reinterpret_cast<u32x4*>(b_lds + buf * kTile + off) = breg[i];
+        }
+    };
+
+    f32x16 acc[2][2];   // [cout sub-tile mi][pixel sub-tile ni]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool has_next = step + 1 < nsteps;
+        if (has_next) stage_load(step + 1);
+        const char* ab = a_lds + cur * kTile;
+        const char* bb = b_lds + cur * kTile;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfg[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(ab + lds_off(wm * 64 + i * 32 + r, 2 * ks + hh));
+                bfg[i] = *reinterpret_cast<const bf16x8*>(bb + lds_off(wn * 64 + i * 32 + r, 2 * ks + hh));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfg[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (has_next) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns pixel column r of each pixel sub-tile; couts 8g + 4hh + 0..3 per register group
+    const int cout2 = p.interleave ? p.Cout / 2 : p.Cout;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t m = m0 + wn * 64 + ni * 32 + r;
+        if (m >= p.M) continue;
+        int64_t opix = m;   // output pixel index in the (possibly time-interleaved) output
+        int64_t frame_stride = 0;
+        if (p.interleave) {
+            const int64_t hw = (int64_t)p.H * p.W;
+            const int64_t t = m / hw;
+            opix = (2 * t) * hw + (m - t * hw);
+            frame_stride = hw;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = c0 + wm * 64 + mi * 32 + 8 * g + 4 * hh;
+                if (co >= p.Cout) continue;
+                int oc = co;
+                int64_t op = opix;
+                if (p.interleave && co >= cout2) { oc = co - cout2; op = opix + frame_stride; }
+                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + co);
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = rbf(acc[mi][ni][4 * g + j] + (float)bv[j]);
+                bf16* dst = p.out + op * cout2 + oc;
+                if (p.residual != nullptr) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + op * cout2 + oc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o4[j] += (float)rv[j];
+                }
+                bf16x4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = (bf16)o4[j];
+                *reinterpret_cast<bf16x4*>(dst) = w4;
+            }
+    }
+}
+
+__global__ void pack_weight_kernel(const bf16* __restrict__ w, bf16* __restrict__ packed, int Cout, int Cin, int ntaps,
+                                   int cout_pad, int cin_pad) {
+    const int64_t total = (int64_t)ntaps * cout_pad * cin_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin_pad);
+        const int co = (int)((i / cin_pad) % cout_pad);
+        const int tap = (int)(i / ((int64_t)cin_pad * cout_pad));
+        bf16 val = (bf16)0.f;
+        if (ci < Cin && co < Cout) val = w[((int64_t)co * Cin + ci) * ntaps + tap];
+        packed[i] = val;
+    }
+}
+
+inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t fg_conv_packed_bytes(int Cout, int Cin, int kt, int kh, int kw) {
+    if (Cout <= 0 || Cin <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (int64_t)kt * kh * kw * roundup(Cout, kBMc) * roundup(Cin, kBK) * 2;
+}
+
+int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int kt, int kh, int kw, fg_stream_t stream) {
+    FG_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && kt > 0 && kh > 0 && kw > 0, "fg_conv_pack_weight_bf16: bad arguments");
+    const int ntaps = kt * kh * kw;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, (bf16*)packed, Cout,
+                       Cin, ntaps, roundup(Cout, kBMc), roundup(Cin, kBK));
+    return fg_launch_status("fg_conv_pack_weight_bf16");
+}
+
+int fg_conv3d_cl_bf16(const void* x, const void* prev, const void* w_packed, const void* bias, const void* residual,
+                      void* out, int T, int H, int W, int Cin, int Cout, int kt, int ks, int upsample2x,
+                      int time_interleave, fg_stream_t stream) {
+    FG_CHECK_ARG(x && w_packed && bias && out, "fg_conv3d_cl_bf16: null pointer");
+    FG_CHECK_ARG(T > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "fg_conv3d_cl_bf16: sizes must be positive");
+    FG_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "fg_conv3d_cl_bf16: kt and ks must be 1 or 3");
+    FG_CHECK_ARG(Cin % 8 == 0 && Cout % 4 == 0, "fg_conv3d_cl_bf16: Cin %% 8 and Cout %% 4 must be 0 (Cin=%d Cout=%d)", Cin, Cout);
+    FG_CHECK_ARG(!upsample2x || (H % 2 == 0 && W % 2 == 0 && kt == 1), "fg_conv3d_cl_bf16: upsample2x needs even H, W and kt==1");
+    FG_CHECK_ARG(!time_interleave || (Cout % 8 == 0), "fg_conv3d_cl_bf16: time_interleave needs Cout %% 8 == 0");
+    FG_CHECK_ARG(prev == nullptr || kt == 3, "fg_conv3d_cl_bf16: a feature cache only makes sense with kt == 3");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(prev) && FG_ALIGNED16(w_packed) && ((uintptr_t)bias & 7) == 0 &&
+                     ((uintptr_t)residual & 7) == 0 && ((uintptr_t)out & 7) == 0,
+                 "fg_conv3d_cl_bf16: misaligned pointer");
+    ConvParams p;
+    p.x = (const bf16*)x; p.prev = (const bf16*)prev; p.wp = (const bf16*)w_packed; p.bias = (const bf16*)bias;
+    p.residual = (const bf16*)residual; p.out = (bf16*)out;
+    p.T = T; p.H = H; p.W = W; p.Hin = upsample2x ? H / 2 : H; p.Win = upsample2x ? W / 2 : W;
+    p.Cin = Cin; p.Cout = Cout; p.kt = kt; p.ks = ks;
+    p.cin_pad = roundup(Cin, kBK); p.cout_pad = roundup(Cout, kBMc);
+    p.upsample = upsample2x ? 1 : 0; p.interleave = time_interleave ? 1 : 0;
+    p.M = (int64_t)T * H * W;
+    const int64_t blocks = ((p.M + kBNp - 1) / kBNp) * (p.cout_pad / kBMc);
+    FG_CHECK_ARG(blocks < (1ll << 31), "fg_conv3d_cl_bf16: grid too large");
+    hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return fg_launch_status("fg_conv3d_cl_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+"""ctypes binding of libfairygen_hip.so (C ABI: include/fairygen_hip.h).
+
+This is the ONLY compute backend of the package.  There is no CPU or eager-PyTorch fallback: if the
+library is missing, or a tensor is not a contiguous bf16 tensor on a HIP device, the call raises.
+PyTorch is used for device memory, streams and the plain GEMMs (hipBLASLt) only.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfairygen_hip.so")
+_lib = None
+
+ABI_VERSION = 1
+
+_i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes; every function returns int except where noted.  Mirrors include/fairygen_hip.h.
+_SIGNATURES = {
+    "fg_ln_modulate_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
+    "fg_ln_affine_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "fg_gate_residual_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
+    "fg_residual_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
+    "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
+    "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
+    "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp],
+    "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
+    "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "fg_conv_pack_weight_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_conv3d_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_dupup3d_add_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i64, _f32, _vp],
+    "fg_vae_latent_to_cl_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_unpatchify_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_tile_accumulate_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_tile_finalize_bf16": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "fg_video_to_uint8": [_vp, _vp, _i32, _i32, _i32, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes"])
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libfairygen_hip.so (built by __graft_entry__.build() / make -C fairygen_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryError(
+            f"{_LIB_PATH} not found: build it with `make -C fairygen_amd/csrc` (or __graft_entry__.build()). "
+            "fairygen_amd has no CPU / PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.fg_version.restype = ctypes.c_int
+    lib.fg_last_error.restype = ctypes.c_char_p
+    lib.fg_conv_packed_bytes.restype = ctypes.c_int64
+    lib.fg_conv_packed_bytes.argtypes = [_i32] * 5
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = argtypes
+    if lib.fg_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {lib.fg_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HipLibraryError(f"{name} failed ({rc}): {lib.fg_last_error().decode()}")
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(t, name, dtype=torch.bfloat16):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise HipLibraryError(f"{name}: expected a tensor on a HIP device, got {getattr(t, 'device', type(t))} "
+                              "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise HipLibraryError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _rows(t, name):
+    """View (..., C) contiguous as (rows, C)."""
+    _dev(t, name)
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{name}: must be contiguous")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+class ModTable:
+    """AdaLN modulation rows: tensor (mod_rows, K, C) bf16; vector j of row r = table[r, j].
+
+    mod_rows 1 (T2V), 2 (TI2V: tokens < first_rows use row 0) or N (per token)."""
+
+    def __init__(self, table, first_rows=0):
+        _dev(table, "mod table")
+        assert table.dim() == 3 and table.is_contiguous()
+        self.table, self.first_rows = table, int(first_rows)
+        self.mod_rows, self.k, self.c = table.shape
+        self.ld = self.k * self.c
+
+    def vec(self, j):
+        return ctypes.c_void_p(self.table.data_ptr() + 2 * j * self.c)
+
+
+def _mod_args(mod, rows):
+    if mod.mod_rows not in (1, 2, rows):
+        raise HipLibraryError(f"modulation table has {mod.mod_rows} rows; expected 1, 2 or {rows}")
+    return mod.mod_rows, mod.first_rows, mod.ld
+
+
+# ------------------------------------------------------------------------------------- DiT kernels
+def ln_modulate(x, mod, shift_idx, scale_idx, eps, out=None):
+    rows, c = _rows(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    _call("fg_ln_modulate_bf16", _ptr(x), mod.vec(shift_idx), mod.vec(scale_idx), _ptr(out), rows, c, eps,
+          *_mod_args(mod, rows), _stream(x))
+    return out
+
+
+def ln_affine(x, w, b, eps, out=None):
+    rows, c = _rows(x, "x")
+    _dev(w, "w"), _dev(b, "b")
+    out = torch.empty_like(x) if out is None else out
+    _call("fg_ln_affine_bf16", _ptr(x), _ptr(w), _ptr(b), _ptr(out), rows, c, eps, _stream(x))
+    return out
+
+
+def gate_residual(x, y, mod=None, gate_idx=None, out=None):
+    rows, c = _rows(x, "x")
+    _rows(y, "y")
+    out = torch.empty_like(x) if out is None else out
+    if mod is None:
+        _call("fg_gate_residual_bf16", _ptr(x), _ptr(y), None, _ptr(out), rows, c, 1, 0, 0, _stream(x))
+    else:
+        _call("fg_gate_residual_bf16", _ptr(x), _ptr(y), mod.vec(gate_idx), _ptr(out), rows, c,
+              *_mod_args(mod, rows), _stream(x))
+    return out
+
+
+def residual_ln_modulate(x, y, mod, gate_idx, shift_idx, scale_idx, eps, x_out=None, norm_out=None, norm_mod=None):
+    """x_out = x + gate*y (gate_idx None: x + y); norm_out = modulate(LN(x_out)).
+
+    gate comes from `mod`, shift/scale from `norm_mod` (default: `mod`); both tables must have the same
+    number of rows, first_rows and leading dimension."""
+    rows, c = _rows(x, "x")
+    _rows(y, "y")
+    norm_mod = mod if norm_mod is None else norm_mod
+    if (norm_mod.mod_rows, norm_mod.first_rows, norm_mod.ld) != (mod.mod_rows, mod.first_rows, mod.ld):
+        raise HipLibraryError("residual_ln_modulate: gate and norm tables must share rows / first_rows / ld")
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    norm_out = torch.empty_like(x) if norm_out is None else norm_out
+    gate = mod.vec(gate_idx) if gate_idx is not None else None
+    _call("fg_residual_ln_bf16", _ptr(x), _ptr(y), gate, _ptr(x_out), norm_mod.vec(shift_idx),
+          norm_mod.vec(scale_idx), _ptr(norm_out), 0, rows, c, eps, *_mod_args(mod, rows), _stream(x))
+    return x_out, norm_out
+
+
+def residual_ln_affine(x, y, w, b, eps, mod=None, gate_idx=None, x_out=None, norm_out=None):
+    """x_out = x + gate*y (mod None: x + y); norm_out = LN(x_out)*w + b."""
+    rows, c = _rows(x, "x")
+    _rows(y, "y")
+    _dev(w, "w"), _dev(b, "b")
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    norm_out = torch.empty_like(x) if norm_out is None else norm_out
+    if mod is None:
+        gate, margs = None, (1, 0, 0)
+    else:
+        gate, margs = mod.vec(gate_idx), _mod_args(mod, rows)
+    _call("fg_residual_ln_bf16", _ptr(x), _ptr(y), gate, _ptr(x_out), _ptr(w), _ptr(b), _ptr(norm_out), 1, rows, c,
+          eps, *margs, _stream(x))
+    return x_out, norm_out
+
+
+def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None):
+    """x: (..., C) possibly a column slice of a wider row-major buffer (stride(-2) = ld)."""
+    _dev(x, "x"), _dev(weight, "weight")
+    c = x.shape[-1]
+    if x.stride(-1) != 1:
+        raise HipLibraryError("rmsnorm_rope: last dim must be dense")
+    x2 = x.reshape(-1, c) if x.is_contiguous() else x
+    if x2.dim() != 2:
+        x2 = x2.squeeze(0)
+    if x2.dim() != 2:
+        raise HipLibraryError("rmsnorm_rope: strided input must be 2-D (rows, C) or (1, rows, C)")
+    rows, ld = x2.shape[0], x2.stride(0)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    if cos is not None:
+        _dev(cos, "cos", torch.float64), _dev(sin, "sin", torch.float64)
+        if cos.shape != (rows, c // num_heads // 2) or not cos.is_contiguous() or not sin.is_contiguous():
+            raise HipLibraryError(f"rmsnorm_rope: rope tables must be ({rows}, {c // num_heads // 2}) contiguous")
+    _call("fg_rmsnorm_rope_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), _ptr(out), rows, c, num_heads,
+          eps, _stream(x))
+    return out
+
+
+def activation(x, kind, out=None):
+    _dev(x, "x")
+    if not x.is_contiguous():
+        raise HipLibraryError("activation: must be contiguous")
+    out = x if out is None else out
+    _call("fg_act_bf16", _ptr(x), _ptr(out), x.numel(), {"silu": 0, "gelu_tanh": 1}[kind], _stream(x))
+    return out
+
+
+def _ld_rows(t, name):
+    """(B, N, HD) with dense last dim and B stride = N*ld."""
+    _dev(t, name)
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise HipLibraryError(f"{name}: expected (B, N, H*D) with dense last dim")
+    ld = t.stride(1)
+    if t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld:
+        raise HipLibraryError(f"{name}: batch stride must be N*ld")
+    return ld
+
+
+def attention(q, k, v, num_heads, out=None):
+    """softmax(q k^T / sqrt(d)) v, "b s (n d)" in and out (AttentionModule semantics)."""
+    ldq, ldk, ldv = _ld_rows(q, "q"), _ld_rows(k, "k"), _ld_rows(v, "v")
+    b, nq, hd = q.shape
+    nkv = k.shape[1]
+    d = hd // num_heads
+    out = torch.empty((b, nq, hd), dtype=q.dtype, device=q.device) if out is None else out
+    _call("fg_attn_fwd_bf16", _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), b, nq, nkv, num_heads, d,
+          float(d) ** -0.5, _stream(q))
+    return out
+
+
+def cfg_euler(latents, posi, nega, cfg_scale, dsigma, out=None):
+    _dev(latents, "latents"), _dev(posi, "posi")
+    assert latents.is_contiguous() and posi.is_contiguous() and (nega is None or nega.is_contiguous())
+    out = torch.empty_like(latents) if out is None else out
+    _call("fg_cfg_euler_bf16", _ptr(latents), _ptr(posi), _ptr(nega), _ptr(out), latents.numel(), float(cfg_scale),
+          float(dsigma), _stream(latents))
+    return out
+
+
+# ------------------------------------------------------------------------------------- VAE kernels
+def vae_rmsnorm_silu(x, gamma, silu=True, out=None):
+    pixels, c = _rows(x, "x")
+    _dev(gamma, "gamma")
+    out = torch.empty_like(x) if out is None else out
+    _call("fg_vae_rmsnorm_silu_bf16", _ptr(x), _ptr(gamma), _ptr(out), pixels, c, int(silu), _stream(x))
+    return out
+
+
+def conv_pack_weight(w):
+    """(Cout,Cin,kt,kh,kw) or (Cout,Cin,kh,kw) bf16 -> packed buffer for conv3d_cl."""
+    _dev(w, "w")
+    w = w.contiguous()
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kt, kh, kw = w.shape
+    nbytes = load().fg_conv_packed_bytes(cout, cin, kt, kh, kw)
+    packed = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _call("fg_conv_pack_weight_bf16", _ptr(w), _ptr(packed), cout, cin, kt, kh, kw, _stream(w))
+    return packed
+
+
+def conv3d_cl(x, w_packed, bias, cout, kt, ks, prev=None, residual=None, upsample2x=False, time_interleave=False,
+              out=None):
+    """x (T,Hin,Win,Cin) channels-last -> (T,H,W,Cout) [or (2T,H,W,Cout/2) with time_interleave]."""
+    _dev(x, "x"), _dev(w_packed, "w_packed"), _dev(bias, "bias")
+    assert x.dim() == 4 and x.is_contiguous()
+    t, hin, win, cin = x.shape
+    h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
+    oshape = (2 * t, h, w, cout // 2) if time_interleave else (t, h, w, cout)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else out
+    assert tuple(out.shape) == oshape and out.is_contiguous()
+    if prev is not None:
+        _dev(prev, "prev")
+        assert tuple(prev.shape) == (2, hin, win, cin) and prev.is_contiguous()
+    if residual is not None:
+        _dev(residual, "residual")
+        assert tuple(residual.shape) == oshape and residual.is_contiguous()
+    _call("fg_conv3d_cl_bf16", _ptr(x), _ptr(prev), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(out), t, h, w,
+          cin, cout, kt, ks, int(upsample2x), int(time_interleave), _stream(x))
+    return out
+
+
+def dupup3d_add(x, main, cout, ft, fs, first_chunk, out=None):
+    _dev(x, "x"), _dev(main, "main")
+    t, h, w, cin = x.shape
+    oshape = (t * ft - (ft - 1 if first_chunk else 0), h * fs, w * fs, cout)
+    assert tuple(main.shape) == oshape and main.is_contiguous() and x.is_contiguous()
+    out = torch.empty_like(main) if out is None else out
+    _call("fg_dupup3d_add_bf16", _ptr(x), _ptr(main), _ptr(out), t, h, w, cin, cout, ft, fs, int(first_chunk),
+          _stream(x))
+    return out
+
+
+def softmax_rows(scores, scale):
+    _dev(scores, "scores", torch.float32)
+    assert scores.dim() == 2 and scores.is_contiguous()
+    probs = torch.empty(scores.shape, dtype=torch.bfloat16, device=scores.device)
+    _call("fg_softmax_rows_f32_bf16", _ptr(scores), _ptr(probs), scores.shape[0], scores.shape[1], float(scale),
+          _stream(scores))
+    return probs
+
+
+def vae_latent_to_cl(z, mean, inv_std):
+    """(C,T,H,W) -> (T,H,W,C) de-normalised."""
+    _dev(z, "z"), _dev(mean, "mean"), _dev(inv_std, "inv_std")
+    assert z.dim() == 4 and z.is_contiguous()
+    c, t, h, w = z.shape
+    out = torch.empty((t, h, w, c), dtype=z.dtype, device=z.device)
+    _call("fg_vae_latent_to_cl_bf16", _ptr(z), _ptr(mean), _ptr(inv_std), _ptr(out), c, t, h, w, _stream(z))
+    return out
+
+
+def vae_unpatchify(x, video, t0, clamp):
+    """x (T,H,W,12) -> video[:, t0:t0+T] of (3,F,2H,2W)."""
+    _dev(x, "x"), _dev(video, "video")
+    t, h, w, c = x.shape
+    assert c == 12 and x.is_contiguous() and video.is_contiguous()
+    assert video.shape[0] == 3 and video.shape[2] == 2 * h and video.shape[3] == 2 * w
+    _call("fg_vae_unpatchify_bf16", _ptr(x), _ptr(video), t, h, w, video.shape[1], t0, int(clamp), _stream(x))
+    return video
+
+
+def vae_tile_accumulate(tile, values, weight, y0, x0, border_h, border_w, bounds):
+    _dev(tile, "tile"), _dev(values, "values"), _dev(weight, "weight")
+    _, f, th, tw = tile.shape
+    _, _, hv, wv = values.shape
+    assert tile.is_contiguous() and values.is_contiguous() and weight.is_contiguous()
+    bits = sum(1 << i for i, bnd in enumerate(bounds) if bnd)
+    _call("fg_vae_tile_accumulate_bf16", _ptr(tile), _ptr(values), _ptr(weight), f, hv, wv, th, tw, y0, x0,
+          border_h, border_w, bits, _stream(tile))
+
+
+def vae_tile_finalize(values, weight):
+    _, f, hv, wv = values.shape
+    _call("fg_vae_tile_finalize_bf16", _ptr(values), _ptr(weight), f, hv, wv, _stream(values))
+    return values
+
+
+def video_to_uint8(video):
+    """(3,F,H,W) bf16 in [-1,1] -> (F,H,W,3) uint8."""
+    _dev(video, "video")
+    assert video.is_contiguous()
+    _, f, h, w = video.shape
+    out = torch.empty((f, h, w, 3), dtype=torch.uint8, device=video.device)
+    _call("fg_video_to_uint8", _ptr(video), _ptr(out), f, h, w, _stream(video))
+    return out

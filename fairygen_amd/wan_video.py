@@ -1,0 +1,364 @@
+"""WanVideoPipeline for the FairyGen animation hot path on MI355X.
+
+Drop-in for what ``animation/inference.py:9-30`` touches of ``diffsynth/pipelines/wan_video.py``:
+``WanVideoPipeline.from_pretrained(torch_dtype, device, model_configs=[ModelConfig...])`` :98-169,
+``pipe.load_lora(pipe.dit, path, alpha=)`` (``diffusion/base_pipeline.py:231-266``),
+``pipe(prompt=, negative_prompt=, input_image=, num_frames=, seed=, tiled=, ...)`` :173-329 and the plug points
+``pipe.model_fn`` / ``pipe.units`` / ``pipe.dit`` / ``pipe.vae`` / ``pipe.scheduler``.
+``model_fn_wan_video`` is the TI2V-5B branch of :1122-1388; the other Wan variants' units (S2V, VACE, VAP,
+Animate, FunControl, camera, LongCat) are out of scope and their kwargs raise.
+
+Extensions (the only additions to the call surface, both optional):
+  * ``prompt`` / ``negative_prompt`` may be pre-embedded context tensors ``(1, L, text_dim)`` — the umT5
+    encoder + tokenizer are a later §8(f) row and need downloaded assets;
+  * ``first_frame_latents=`` supplies the TI2V conditioning latent directly while the VAE encoder row is
+    pending (``input_image`` then needs ``pipe.vae.encode``).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from PIL import Image
+from tqdm import tqdm
+
+from . import hip
+from .flow_match import FlowMatchScheduler
+from .loader import ModelConfig, ModelPool, load_state_dict
+from .lora import GeneralLoRALoader
+from .wan_video_dit import WanModel, sinusoidal_embedding_1d
+
+
+# ------------------------------------------------------------------------------------ pipeline units
+class PipelineUnit:
+    """diffusion/base_pipeline.py:12-56 — declarative (inputs -> outputs) step run before the loop."""
+
+    def __init__(self, seperate_cfg=False, take_over=False, input_params=None, output_params=None,
+                 input_params_posi=None, input_params_nega=None, onload_model_names=None):
+        self.seperate_cfg, self.take_over = seperate_cfg, take_over
+        self.input_params, self.output_params = input_params, output_params
+        self.input_params_posi, self.input_params_nega = input_params_posi, input_params_nega
+        self.onload_model_names = onload_model_names
+
+    def process(self, pipe, **kwargs):
+        return {}
+
+
+class PipelineUnitRunner:
+    """diffusion/base_pipeline.py:411-441."""
+
+    def __call__(self, unit, pipe, inputs_shared, inputs_posi, inputs_nega):
+        if unit.take_over:
+            return unit.process(pipe, inputs_shared=inputs_shared, inputs_posi=inputs_posi, inputs_nega=inputs_nega)
+        if unit.seperate_cfg:
+            shared = {n: inputs_shared.get(n) for n in (unit.input_params or ())}
+            out = unit.process(pipe, **{n: inputs_posi.get(src) for n, src in unit.input_params_posi.items()}, **shared)
+            inputs_posi.update(out)
+            if inputs_shared["cfg_scale"] != 1:
+                out = unit.process(pipe, **{n: inputs_nega.get(src) for n, src in unit.input_params_nega.items()}, **shared)
+            inputs_nega.update(out)
+        else:
+            inputs_shared.update(unit.process(pipe, **{n: inputs_shared.get(n) for n in unit.input_params}))
+        return inputs_shared, inputs_posi, inputs_nega
+
+
+class WanVideoUnit_ShapeChecker(PipelineUnit):
+    def __init__(self):
+        super().__init__(input_params=("height", "width", "num_frames"), output_params=("height", "width", "num_frames"))
+
+    def process(self, pipe, height, width, num_frames):
+        height, width, num_frames = pipe.check_resize_height_width(height, width, num_frames)
+        return {"height": height, "width": width, "num_frames": num_frames}
+
+
+class WanVideoUnit_NoiseInitializer(PipelineUnit):
+    def __init__(self):
+        super().__init__(input_params=("height", "width", "num_frames", "seed", "rand_device"), output_params=("noise",))
+
+    def process(self, pipe, height, width, num_frames, seed, rand_device):
+        length = (num_frames - 1) // 4 + 1
+        shape = (1, pipe.vae.model.z_dim, length, height // pipe.vae.upsampling_factor, width // pipe.vae.upsampling_factor)
+        return {"noise": pipe.generate_noise(shape, seed=seed, rand_device=rand_device)}
+
+
+class WanVideoUnit_PromptEmbedder(PipelineUnit):
+    def __init__(self):
+        super().__init__(seperate_cfg=True, input_params_posi={"prompt": "prompt"},
+                         input_params_nega={"prompt": "negative_prompt"}, output_params=("context",),
+                         onload_model_names=("text_encoder",))
+
+    def process(self, pipe, prompt):
+        if isinstance(prompt, torch.Tensor):          # pre-embedded context (extension, see module docstring)
+            return {"context": prompt.to(dtype=pipe.torch_dtype, device=pipe.device)}
+        if pipe.text_encoder is None or pipe.tokenizer is None:
+            raise RuntimeError("no text encoder / tokenizer loaded (umT5 is a later hot-path row and needs downloaded "
+                               "assets): pass prompt= and negative_prompt= as (1, L, text_dim) context tensors")
+        ids, mask = pipe.tokenizer(prompt, return_mask=True, add_special_tokens=True)
+        ids, mask = ids.to(pipe.device), mask.to(pipe.device)
+        seq_lens = mask.gt(0).sum(dim=1).long()
+        emb = pipe.text_encoder(ids, mask)
+        for v in seq_lens:
+            emb[:, v:] = 0
+        return {"context": emb}
+
+
+class WanVideoUnit_InputVideoEmbedder(PipelineUnit):
+    def __init__(self):
+        super().__init__(input_params=("input_video", "noise"), output_params=("latents",))
+
+    def process(self, pipe, input_video, noise):
+        if input_video is not None:
+            raise NotImplementedError("video-to-video needs the VAE encoder (next hot-path row)")
+        return {"latents": noise}
+
+
+class WanVideoUnit_ImageEmbedderFused(PipelineUnit):
+    """TI2V-5B conditioning: first latent frame = encoded image, re-pinned every step (:479-497)."""
+
+    def __init__(self):
+        super().__init__(input_params=("input_image", "first_frame_latents", "latents", "height", "width", "tiled",
+                                       "tile_size", "tile_stride"),
+                         output_params=("latents", "fuse_vae_embedding_in_latents", "first_frame_latents"),
+                         onload_model_names=("vae",))
+
+    def process(self, pipe, input_image, first_frame_latents, latents, height, width, tiled, tile_size, tile_stride):
+        if not pipe.dit.fuse_vae_embedding_in_latents or (input_image is None and first_frame_latents is None):
+            return {}
+        if first_frame_latents is None:
+            image = pipe.preprocess_image(input_image.resize((width, height))).transpose(0, 1)
+            first_frame_latents = pipe.vae.encode([image], device=pipe.device, tiled=tiled, tile_size=tile_size,
+                                                  tile_stride=tile_stride)
+        z = first_frame_latents.to(dtype=pipe.torch_dtype, device=pipe.device)
+        latents[:, :, 0:1] = z
+        return {"latents": latents, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z}
+
+
+_OUT_OF_SCOPE_KWARGS = (
+    "end_image", "input_video", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
+    "control_video", "reference_image", "camera_control_direction", "vace_video", "vace_video_mask",
+    "vace_reference_image", "animate_pose_video", "animate_face_video", "animate_inpaint_video", "animate_mask_video",
+    "vap_video", "motion_bucket_id", "longcat_video", "sliding_window_size", "sliding_window_stride", "tea_cache_l1_thresh",
+)
+
+
+class WanVideoPipeline(torch.nn.Module):
+    def __init__(self, device="cuda", torch_dtype=torch.bfloat16):
+        super().__init__()
+        self.device, self.torch_dtype = device, torch_dtype
+        self.height_division_factor = self.width_division_factor = 16
+        self.time_division_factor, self.time_division_remainder = 4, 1
+        self.vram_management_enabled = False
+        self.unit_runner = PipelineUnitRunner()
+        self.lora_loader = GeneralLoRALoader
+        self.scheduler = FlowMatchScheduler("Wan")
+        self.tokenizer = None
+        self.text_encoder = None
+        self.dit: WanModel = None
+        self.dit2 = None
+        self.vae = None
+        self.in_iteration_models = ("dit",)
+        self.units = [
+            WanVideoUnit_ShapeChecker(),
+            WanVideoUnit_NoiseInitializer(),
+            WanVideoUnit_PromptEmbedder(),
+            WanVideoUnit_InputVideoEmbedder(),
+            WanVideoUnit_ImageEmbedderFused(),
+        ]
+        self.post_units = []
+        self.model_fn = model_fn_wan_video
+        self.sequence_shard = None          # set by enable_sequence_parallel()
+        self.use_unified_sequence_parallel = False
+
+    # ----------------------------------------------------------------------------- construction
+    @staticmethod
+    def from_pretrained(torch_dtype=torch.bfloat16, device="cuda", model_configs=[], tokenizer_config=None,
+                        audio_processor_config=None, redirect_common_files=True, use_usp=False, vram_limit=None):
+        pipe = WanVideoPipeline(device=device, torch_dtype=torch_dtype)
+        pool = pipe.download_and_load_models(model_configs, vram_limit)
+        pipe.text_encoder = pool.fetch_model("wan_video_text_encoder")
+        dit = pool.fetch_model("wan_video_dit", index=2)
+        if isinstance(dit, list):
+            raise NotImplementedError("two-expert (dit/dit2) Wan2.2-A14B checkpoints are outside the TI2V-5B hot path")
+        pipe.dit = dit
+        pipe.vae = pool.fetch_model("wan_video_vae")
+        if pipe.vae is not None:
+            pipe.height_division_factor = pipe.width_division_factor = pipe.vae.upsampling_factor * 2
+        if tokenizer_config is not None:
+            tokenizer_config.download_if_necessary()
+            raise NotImplementedError("HuggingfaceTokenizer plumbing arrives with the umT5 row; pass context tensors")
+        if use_usp:
+            pipe.enable_usp()
+        return pipe
+
+    def download_and_load_models(self, model_configs=[], vram_limit=None):
+        pool = ModelPool()
+        for cfg in model_configs:
+            cfg.download_if_necessary()
+            vram = cfg.vram_config()
+            vram["computation_dtype"] = vram["computation_dtype"] or self.torch_dtype
+            vram["computation_device"] = vram["computation_device"] or self.device
+            pool.auto_load_model(cfg.path, vram_config=vram, vram_limit=vram_limit, clear_parameters=cfg.clear_parameters)
+        return pool
+
+    def enable_usp(self):
+        """The reference's use_usp=True monkey-patches xfuser Ulysses attention (:84-95); here the same switch
+        turns on latent-temporal token sharding with an RCCL K/V all-gather (sequence_parallel.py)."""
+        return self.enable_sequence_parallel()
+
+    def enable_sequence_parallel(self, group=None):
+        from .sequence_parallel import TokenShard
+        self.sequence_shard = TokenShard(group)
+        self.use_unified_sequence_parallel = True
+        return self
+
+    # ----------------------------------------------------------------------------- BasePipeline helpers
+    def check_resize_height_width(self, height, width, num_frames=None):
+        hf, wf = self.height_division_factor, self.width_division_factor
+        if height % hf != 0:
+            height = (height + hf - 1) // hf * hf
+            print(f"height % {hf} != 0. We round it up to {height}.")
+        if width % wf != 0:
+            width = (width + wf - 1) // wf * wf
+            print(f"width % {wf} != 0. We round it up to {width}.")
+        if num_frames is None:
+            return height, width
+        tf, tr = self.time_division_factor, self.time_division_remainder
+        if num_frames % tf != tr:
+            num_frames = (num_frames + tf - 1) // tf * tf + tr
+            print(f"num_frames % {tf} != {tr}. We round it up to {num_frames}.")
+        return height, width, num_frames
+
+    def preprocess_image(self, image, torch_dtype=None, device=None, min_value=-1, max_value=1):
+        """PIL -> (1,C,H,W) in [min,max] (base_pipeline.py:112-118)."""
+        x = torch.Tensor(np.array(image, dtype=np.float32)).to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
+        x = x * ((max_value - min_value) / 255) + min_value
+        return x.permute(2, 0, 1).unsqueeze(0)
+
+    def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None, torch_dtype=None):
+        generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
+        noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
+        return noise.to(dtype=torch_dtype or self.torch_dtype, device=device or self.device)
+
+    def vae_output_to_video(self, vae_output):
+        """(1,3,F,H,W) in [-1,1] -> list of PIL frames; the uint8 conversion (truncation) runs on the device."""
+        frames = hip.video_to_uint8(vae_output[0].contiguous()).cpu().numpy()
+        return [Image.fromarray(f) for f in frames]
+
+    def load_models_to_device(self, model_names):
+        pass        # models stay resident in HBM (no VRAM management on this path)
+
+    def load_lora(self, module, lora_config=None, alpha=1, hotload=None, state_dict=None):
+        if hotload:
+            raise ValueError("VRAM Management is not enabled. LoRA hotloading is not supported.")
+        if state_dict is None:
+            if isinstance(lora_config, str):
+                lora = load_state_dict(lora_config, torch_dtype=self.torch_dtype, device=self.device)
+            else:
+                lora_config.download_if_necessary()
+                lora = load_state_dict(lora_config.path, torch_dtype=self.torch_dtype, device=self.device)
+        else:
+            lora = state_dict
+        loader = self.lora_loader(torch_dtype=self.torch_dtype, device=self.device)
+        loader.fuse_lora_to_base_model(module, loader.convert_state_dict(lora), alpha=alpha)
+
+    def clear_lora(self):
+        print("0 LoRA layers are cleared.")      # fused LoRA cannot be cleared (same as the reference)
+
+    # ----------------------------------------------------------------------------- __call__
+    @torch.no_grad()
+    def __call__(self, prompt, negative_prompt="", input_image=None, seed=None, rand_device="cpu", height=480, width=832,
+                 num_frames=81, cfg_scale=5.0, cfg_merge=False, switch_DiT_boundary=0.875, num_inference_steps=50,
+                 sigma_shift=5.0, denoising_strength=1.0, tiled=True, tile_size=(30, 52), tile_stride=(15, 26),
+                 progress_bar_cmd=tqdm, output_type="quantized", first_frame_latents=None, **other):
+        for name, value in other.items():
+            if name not in _OUT_OF_SCOPE_KWARGS:
+                raise TypeError(f"__call__() got an unexpected keyword argument {name!r}")
+            if value is not None:
+                raise NotImplementedError(f"{name}= belongs to another Wan variant / feature outside the TI2V-5B hot path")
+        if cfg_merge:
+            raise NotImplementedError("cfg_merge=True (batched CFG) is not on the reference inference.py path")
+        self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+
+        inputs_posi = {"prompt": prompt}
+        inputs_nega = {"negative_prompt": negative_prompt}
+        inputs_shared = {
+            "input_image": input_image, "first_frame_latents": first_frame_latents, "input_video": None,
+            "seed": seed, "rand_device": rand_device, "height": height, "width": width, "num_frames": num_frames,
+            "cfg_scale": cfg_scale, "cfg_merge": cfg_merge, "sigma_shift": sigma_shift,
+            "tiled": tiled, "tile_size": tile_size, "tile_stride": tile_stride,
+        }
+        for unit in self.units:
+            inputs_shared, inputs_posi, inputs_nega = self.unit_runner(unit, self, inputs_shared, inputs_posi, inputs_nega)
+
+        # Denoise (reference :283-309)
+        latents = self.denoise(inputs_shared, inputs_posi, inputs_nega, cfg_scale, progress_bar_cmd)
+        inputs_shared["latents"] = latents
+        for unit in self.post_units:
+            inputs_shared, _, _ = self.unit_runner(unit, self, inputs_shared, inputs_posi, inputs_nega)
+
+        # Decode (reference :322-325)
+        video = self.vae.decode(inputs_shared["latents"], device=self.device, tiled=tiled, tile_size=tile_size,
+                                tile_stride=tile_stride)
+        if output_type == "quantized":
+            video = self.vae_output_to_video(video)
+        return video
+
+    def denoise(self, inputs_shared, inputs_posi, inputs_nega, cfg_scale, progress_bar_cmd=tqdm):
+        """The hot loop: per step forward(+), forward(-), then CFG combine + Euler step fused in one HIP kernel,
+        then the first latent frame re-pinned (TI2V)."""
+        models = {name: getattr(self, name) for name in self.in_iteration_models}
+        shared = {k: v for k, v in inputs_shared.items() if k in ("latents", "fuse_vae_embedding_in_latents")}
+        shared["sequence_shard"] = self.sequence_shard
+        latents = inputs_shared["latents"].contiguous()
+        first = inputs_shared.get("first_frame_latents")
+        for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
+            ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
+            shared["latents"] = latents
+            posi = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_posi), timestep=ts)
+            nega = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_nega), timestep=ts) if cfg_scale != 1.0 else None
+            sigma, sigma_next = self.scheduler.step_scalars(self.scheduler.timesteps[progress_id])
+            latents = hip.cfg_euler(latents, posi.contiguous(), None if nega is None else nega.contiguous(),
+                                    cfg_scale, float(sigma_next - sigma))
+            if first is not None:
+                latents[:, :, 0:1] = first
+        return latents
+
+
+def inputs_posi_ctx(d):
+    return {"context": d["context"]}
+
+
+# ------------------------------------------------------------------------------------- the DiT forward
+def model_fn_wan_video(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
+                       sequence_shard=None, **kwargs):
+    """One DiT forward (TI2V-5B / T2V branches of pipelines/wan_video.py:1217-1388).
+
+    timestep: (1,) tensor already rounded to the pipeline dtype (host or device).  The per-token time embedding of
+    the reference (:1219-1228) has only two distinct rows (t=0 for the first latent frame, t elsewhere): both rows
+    go through time_embedding / time_projection once and the kernels index them by token position.
+    """
+    assert latents.shape[0] == 1, "batch 1 (cfg_merge is not on the hot path)"
+    dev, dt = latents.device, latents.dtype
+    tval = timestep.detach().to("cpu")
+    ti2v = dit.seperated_timestep and fuse_vae_embedding_in_latents
+    t_pos = torch.cat([torch.zeros(1, dtype=tval.dtype), tval]) if ti2v else tval
+    emb = sinusoidal_embedding_1d(dit.freq_dim, t_pos).to(device=dev, dtype=dt)         # (R, freq_dim)
+    te = dit.time_embedding
+    t_rows = F.linear(hip.activation(F.linear(emb, te[0].weight, te[0].bias), "silu"), te[2].weight, te[2].bias)
+    proj = dit.time_projection[1]
+    mod_rows_t = F.linear(hip.activation(t_rows.clone(), "silu"), proj.weight, proj.bias).unflatten(1, (6, dit.dim))
+
+    tx = dit.text_embedding
+    ctx = F.linear(hip.activation(F.linear(context, tx[0].weight, tx[0].bias), "gelu_tanh"), tx[2].weight, tx[2].bias)
+
+    x, (f, h, w) = dit.patchify(latents)
+    n = f * h * w
+    first_rows = h * w if ti2v else 0
+    cos, sin = dit.rope_tables(f, h, w, dev)
+    if sequence_shard is not None and sequence_shard.world_size > 1:
+        lo, hi = sequence_shard.local_range(n)
+        x_loc = x[:, lo:hi].contiguous()
+        out_loc = dit.forward_tokens(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
+                                     (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n)
+        out = sequence_shard.all_gather_tokens(out_loc, n)
+    else:
+        out = dit.forward_tokens(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin))
+    return dit.unpatchify(out, (f, h, w))

@@ -1,0 +1,234 @@
+"""Wan2.2-TI2V-5B DiT on MI355X: parameter layout of the reference, compute on the HIP kernels.
+
+Mirror of ``diffsynth/models/wan_video_dit.py`` (``WanModel`` :271-336, ``DiTBlock`` :195-229,
+``SelfAttention`` :123-146, ``CrossAttention`` :149-185, ``Head`` :252-268): same constructor kwargs,
+same parameter names and shapes, so reference checkpoints, LoRA files and the key-hash model
+identification (``core/loader/file.py:117-121``) keep working.  The modules hold parameters only; the
+arithmetic is in ``forward_tokens`` below, built from ``fairygen_amd.hip`` kernels plus hipBLASLt GEMMs
+(``F.linear``).  Nothing here runs on CPU tensors — the HIP library raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+
+def sinusoidal_embedding_1d(dim, position):
+    """fp64 sinusoid [cos | sin] (reference :67-71); position is a small CPU tensor here."""
+    sinusoid = torch.outer(position.to(torch.float64),
+                           torch.pow(10000.0, -torch.arange(dim // 2, dtype=torch.float64).div(dim // 2)))
+    return torch.cat([sinusoid.cos(), sinusoid.sin()], dim=1).to(position.dtype)
+
+
+def precompute_freqs_cis(dim, end=1024, theta=10000.0):
+    """complex128 rotation table of one axis (reference :82-88)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].double() / dim))
+    freqs = torch.outer(torch.arange(end), freqs)
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def precompute_freqs_cis_3d(dim, end=1024, theta=10000.0):
+    """(frame, height, width) tables; head_dim split d-2*(d//3), d//3, d//3 (reference :74-79)."""
+    return (precompute_freqs_cis(dim - 2 * (dim // 3), end, theta),
+            precompute_freqs_cis(dim // 3, end, theta),
+            precompute_freqs_cis(dim // 3, end, theta))
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class AttentionModule(nn.Module):
+    """Plug point (iii) of the reference (:113-120): "b s (n d)" bf16 in and out, on the MFMA kernel."""
+
+    def __init__(self, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+
+    def forward(self, q, k, v):
+        return hip.attention(q, k, v, self.num_heads)
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, eps=1e-6):
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
+        self.attn = AttentionModule(num_heads)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim, num_heads, eps=1e-6, has_image_input=False):
+        super().__init__()
+        if has_image_input:
+            raise NotImplementedError("has_image_input=True (Wan2.1 I2V CLIP branch) is outside the TI2V-5B hot path")
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q, self.norm_k = RMSNorm(dim, eps=eps), RMSNorm(dim, eps=eps)
+        self.has_image_input = has_image_input
+        self.attn = AttentionModule(num_heads)
+
+
+class DiTBlock(nn.Module):
+    def __init__(self, has_image_input, dim, num_heads, ffn_dim, eps=1e-6):
+        super().__init__()
+        self.dim, self.num_heads, self.ffn_dim, self.eps = dim, num_heads, ffn_dim, eps
+        self.self_attn = SelfAttention(dim, num_heads, eps)
+        self.cross_attn = CrossAttention(dim, num_heads, eps, has_image_input=has_image_input)
+        self.norm1 = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.norm2 = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.norm3 = nn.LayerNorm(dim, eps=eps)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+        self._fused = None
+
+    def fused_weights(self):
+        """[Wq;Wk;Wv] and [Wk;Wv] (cross) concatenated once, so the three projections of a token tensor are
+        ONE hipBLASLt GEMM.  Rebuilt after load_state_dict / LoRA fuse (see WanModel.invalidate_fused)."""
+        if self._fused is None:
+            sa, ca = self.self_attn, self.cross_attn
+            self._fused = (
+                torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous(),
+                torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous(),
+                torch.cat([ca.k.weight, ca.v.weight], 0).contiguous(),
+                torch.cat([ca.k.bias, ca.v.bias], 0).contiguous(),
+            )
+        return self._fused
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps):
+        super().__init__()
+        self.dim, self.patch_size, self.eps = dim, patch_size, eps
+        self.norm = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
+        self.head = nn.Linear(dim, out_dim * math.prod(patch_size))
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+
+class WanModel(nn.Module):
+    def __init__(self, dim, in_dim, ffn_dim, out_dim, text_dim, freq_dim, eps, patch_size, num_heads, num_layers,
+                 has_image_input, has_image_pos_emb=False, has_ref_conv=False, add_control_adapter=False,
+                 in_dim_control_adapter=24, seperated_timestep=False, require_vae_embedding=True,
+                 require_clip_embedding=True, fuse_vae_embedding_in_latents=False):
+        super().__init__()
+        if has_image_input or has_ref_conv or add_control_adapter:
+            raise NotImplementedError("CLIP image branch / ref_conv / camera adapter belong to other Wan variants "
+                                      "(out of scope: SURVEY.md §2.1 rows 12)")
+        self.dim, self.in_dim, self.out_dim, self.freq_dim = dim, in_dim, out_dim, freq_dim
+        self.num_heads, self.eps = num_heads, eps
+        self.has_image_input = has_image_input
+        self.patch_size = tuple(patch_size)
+        self.seperated_timestep = seperated_timestep
+        self.require_vae_embedding = require_vae_embedding
+        self.require_clip_embedding = require_clip_embedding
+        self.fuse_vae_embedding_in_latents = fuse_vae_embedding_in_latents
+        self.has_image_pos_emb, self.has_ref_conv, self.control_adapter = has_image_pos_emb, has_ref_conv, None
+
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.blocks = nn.ModuleList([DiTBlock(has_image_input, dim, num_heads, ffn_dim, eps) for _ in range(num_layers)])
+        self.head = Head(dim, out_dim, self.patch_size, eps)
+        self.freqs = precompute_freqs_cis_3d(dim // num_heads)
+        self._rope_cache = {}
+
+    # ------------------------------------------------------------------ load-time hooks
+    def invalidate_fused(self):
+        for blk in self.blocks:
+            blk._fused = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_fused()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_fused()
+        self._rope_cache = {}
+        return out
+
+    # ------------------------------------------------------------------ host-side tables
+    def rope_tables(self, f, h, w, device):
+        """fp64 cos/sin of the per-token complex table, tokens frame-major (pipelines/wan_video.py:1271-1275)."""
+        key = (f, h, w, str(device))
+        if key not in self._rope_cache:
+            tab = torch.cat([
+                self.freqs[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+                self.freqs[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                self.freqs[2][:w].view(1, 1, w, -1).expand(f, h, w, -1),
+            ], dim=-1).reshape(f * h * w, -1)
+            self._rope_cache = {key: (tab.real.contiguous().to(device), tab.imag.contiguous().to(device))}
+        return self._rope_cache[key]
+
+    def patchify(self, x):
+        """Conv3d with kernel == stride == (1,p,p) is a GEMM over unfolded patches; returns frame-major
+        tokens (b, f*h*w, dim) and the grid (reference :338-344 + pipelines/wan_video.py:1260-1261)."""
+        b, c, t, hh, ww = x.shape
+        pt, ph, pw = self.patch_size
+        f, h, w = t // pt, hh // ph, ww // pw
+        cols = x.view(b, c, f, pt, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, f * h * w, c * pt * ph * pw)
+        wmat = self.patch_embedding.weight.view(self.dim, -1)
+        return F.linear(cols, wmat, self.patch_embedding.bias), (f, h, w)
+
+    def unpatchify(self, x, grid_size):
+        """'b (f h w) (x y z c) -> b c (f x) (h y) (w z)' (reference :346-351)."""
+        f, h, w = grid_size
+        px, py, pz = self.patch_size
+        b = x.shape[0]
+        x = x.view(b, f, h, w, px, py, pz, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return x.reshape(b, self.out_dim, f * px, h * py, w * pz)
+
+    # ------------------------------------------------------------------ the 30-block token forward
+    def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
+        """x (1,n,dim) local tokens; context (1,L,dim) embedded text; t_rows (R,dim) distinct time embeddings
+        (R = 1 or 2), mod_rows_t (R,6,dim) their projections; tokens < first_rows use row 0.
+        rope = (cos, sin) for the LOCAL tokens.  shard: optional fairygen_amd.sequence_parallel.TokenShard —
+        K/V are all-gathered over it before self-attention (shard_total = N, all ranks' tokens).  Returns head output (1,n,out*patch)."""
+        c, nh, eps = self.dim, self.num_heads, self.eps
+        cos, sin = rope
+        n = x.shape[1]
+        x = x.contiguous()
+        blocks = list(self.blocks)
+        mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
+        h = hip.ln_modulate(x, mods[0], 0, 1, eps)
+        for i, blk in enumerate(blocks):
+            mod = mods[i]
+            wqkv, bqkv, wkv_c, bkv_c = blk.fused_weights()
+            sa, ca = blk.self_attn, blk.cross_attn
+            # --- self attention (reference :139-146)
+            qkv = F.linear(h, wqkv, bqkv)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
+            v = qkv[..., 2 * c:]
+            if shard is not None:
+                k, v = shard.all_gather_kv(k, v, shard_total)
+            y = F.linear(sa.attn(q, k, v), sa.o.weight, sa.o.bias)
+            # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
+            x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+            # --- cross attention (reference :170-185)
+            qc = hip.rmsnorm_rope(F.linear(h, ca.q.weight, ca.q.bias), ca.norm_q.weight, nh, eps)
+            kvc = F.linear(context, wkv_c, bkv_c)
+            kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
+            y = F.linear(ca.attn(qc, kc, kvc[..., c:]), ca.o.weight, ca.o.bias)
+            # x += y ; h = modulate(norm2(x))  (reference :226-227)
+            x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
+            # --- ffn (reference :208-209,228)
+            y = F.linear(hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh"),
+                         blk.ffn[2].weight, blk.ffn[2].bias)
+            if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
+                x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])
+            else:
+                x = hip.gate_residual(x, y, mod, 5, out=x)
+        # --- head (reference :261-268): table (R,2,C) = modulation + t
+        hm = hip.ModTable((self.head.modulation.to(t_rows.dtype) + t_rows.unsqueeze(1)).contiguous(), first_rows)
+        h = hip.ln_modulate(x, hm, 0, 1, eps)
+        return F.linear(h, self.head.head.weight, self.head.head.bias)

@@ -1,0 +1,361 @@
+"""Wan2.2 VAE ("VAE38") on MI355X: reference parameter layout, decode on the HIP kernels.
+
+Mirror of ``diffsynth/models/wan_video_vae.py``: ``WanVideoVAE38`` :1354-1382, ``VideoVAE38_`` :1269-1351,
+``Decoder3d_38`` :842-940, ``Up_ResidualBlock`` :477-514, ``ResidualBlock`` :267-301, ``Resample38`` :227-265,
+``AttentionBlock`` :304-342, ``DupUp3D`` :398-439, tiling ``WanVideoVAE`` :1081-1152,1235-1247.
+The nn.Modules below are parameter containers with the reference's names/shapes (the encoder's included, so
+``Wan2.2_VAE.pth`` loads and its key hash matches); the decode arithmetic is channels-last (T,H,W,C) on
+``fairygen_amd.hip``: implicit-GEMM MFMA convs with the feature cache, fused RMS_norm·SiLU, fused nearest-2x
+upsample, fused channel->time interleave, fused residual add, on-device tile feathering.
+The chunk loop (one latent frame per step, 2-frame feature cache per causal conv) stays on the host, as in
+the reference; every cache is a zero-initialised (2,H,W,C) ring that frames are shifted into, which is what
+the reference's None / 1-frame / 'Rep' special cases amount to (zero causal padding).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+CACHE_T = 2
+
+
+class CausalConv3d(nn.Conv3d):
+    """Parameter holder (weight (Cout,Cin,kt,kh,kw), bias); compute = hip.conv3d_cl."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._padding = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self.padding = (0, 0, 0)
+
+
+class RMS_norm(nn.Module):
+    def __init__(self, dim, channel_first=True, images=True, bias=False):
+        super().__init__()
+        shape = (dim, *((1, 1, 1) if not images else (1, 1))) if channel_first else (dim,)
+        self.channel_first, self.scale = channel_first, dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones(shape))
+        self.bias = nn.Parameter(torch.zeros(shape)) if bias else 0.0
+
+
+class Upsample(nn.Upsample):
+    pass
+
+
+class Resample38(nn.Module):
+    def __init__(self, dim, mode):
+        assert mode in ("none", "upsample2d", "upsample3d", "downsample2d", "downsample3d")
+        super().__init__()
+        self.dim, self.mode = dim, mode
+        if mode in ("upsample2d", "upsample3d"):
+            self.resample = nn.Sequential(Upsample(scale_factor=(2.0, 2.0), mode="nearest-exact"),
+                                          nn.Conv2d(dim, dim, 3, padding=1))
+            if mode == "upsample3d":
+                self.time_conv = CausalConv3d(dim, dim * 2, (3, 1, 1), padding=(1, 0, 0))
+        elif mode in ("downsample2d", "downsample3d"):
+            self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+            if mode == "downsample3d":
+                self.time_conv = CausalConv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+        else:
+            self.resample = nn.Identity()
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout=0.0):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.residual = nn.Sequential(
+            RMS_norm(in_dim, images=False), nn.SiLU(), CausalConv3d(in_dim, out_dim, 3, padding=1),
+            RMS_norm(out_dim, images=False), nn.SiLU(), nn.Dropout(dropout), CausalConv3d(out_dim, out_dim, 3, padding=1))
+        self.shortcut = CausalConv3d(in_dim, out_dim, 1) if in_dim != out_dim else nn.Identity()
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.norm = RMS_norm(dim)
+        self.to_qkv = nn.Conv2d(dim, dim * 3, 1)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+
+class AvgDown3D(nn.Module):
+    def __init__(self, in_channels, out_channels, factor_t, factor_s=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.factor_t, self.factor_s = in_channels, out_channels, factor_t, factor_s
+
+
+class DupUp3D(nn.Module):
+    def __init__(self, in_channels, out_channels, factor_t, factor_s=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.factor_t, self.factor_s = in_channels, out_channels, factor_t, factor_s
+
+
+class Down_ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout, mult, temperal_downsample=False, down_flag=False):
+        super().__init__()
+        self.avg_shortcut = AvgDown3D(in_dim, out_dim, 2 if temperal_downsample else 1, 2 if down_flag else 1)
+        layers = []
+        for _ in range(mult):
+            layers.append(ResidualBlock(in_dim, out_dim, dropout))
+            in_dim = out_dim
+        if down_flag:
+            layers.append(Resample38(out_dim, mode="downsample3d" if temperal_downsample else "downsample2d"))
+        self.downsamples = nn.Sequential(*layers)
+
+
+class Up_ResidualBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, dropout, mult, temperal_upsample=False, up_flag=False):
+        super().__init__()
+        self.avg_shortcut = DupUp3D(in_dim, out_dim, 2 if temperal_upsample else 1, 2 if up_flag else 1) if up_flag else None
+        layers = []
+        for _ in range(mult):
+            layers.append(ResidualBlock(in_dim, out_dim, dropout))
+            in_dim = out_dim
+        if up_flag:
+            layers.append(Resample38(out_dim, mode="upsample3d" if temperal_upsample else "upsample2d"))
+        self.upsamples = nn.Sequential(*layers)
+
+
+class Encoder3d_38(nn.Module):
+    """Parameters only (first-frame encode is the next §8(f) row; see WanVideoVAE38.encode)."""
+
+    def __init__(self, dim=128, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_downsample=[False, True, True], dropout=0.0):
+        super().__init__()
+        dims = [dim * u for u in [1] + dim_mult]
+        self.conv1 = CausalConv3d(12, dims[0], 3, padding=1)
+        downs = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            t_down = temperal_downsample[i] if i < len(temperal_downsample) else False
+            downs.append(Down_ResidualBlock(in_dim, out_dim, dropout, num_res_blocks, t_down, i != len(dim_mult) - 1))
+        self.downsamples = nn.Sequential(*downs)
+        self.middle = nn.Sequential(ResidualBlock(out_dim, out_dim, dropout), AttentionBlock(out_dim),
+                                    ResidualBlock(out_dim, out_dim, dropout))
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, z_dim, 3, padding=1))
+
+
+class Decoder3d_38(nn.Module):
+    def __init__(self, dim=128, z_dim=4, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_upsample=[False, True, True], dropout=0.0):
+        super().__init__()
+        dims = [dim * u for u in [dim_mult[-1]] + dim_mult[::-1]]
+        self.conv1 = CausalConv3d(z_dim, dims[0], 3, padding=1)
+        self.middle = nn.Sequential(ResidualBlock(dims[0], dims[0], dropout), AttentionBlock(dims[0]),
+                                    ResidualBlock(dims[0], dims[0], dropout))
+        ups = []
+        for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            t_up = temperal_upsample[i] if i < len(temperal_upsample) else False
+            ups.append(Up_ResidualBlock(in_dim, out_dim, dropout, num_res_blocks + 1, t_up, i != len(dim_mult) - 1))
+        self.upsamples = nn.Sequential(*ups)
+        self.head = nn.Sequential(RMS_norm(out_dim, images=False), nn.SiLU(), CausalConv3d(out_dim, 12, 3, padding=1))
+
+
+class _ConvState:
+    """Packed weight + zero-initialised 2-frame feature cache of one conv for one decode."""
+
+    __slots__ = ("packed", "bias", "cout", "kt", "ks", "cache")
+
+    def __init__(self, conv):
+        w = conv.weight
+        self.packed = hip.conv_pack_weight(w)
+        self.bias = conv.bias.contiguous()
+        self.cout = w.shape[0]
+        self.kt = w.shape[2] if w.dim() == 5 else 1
+        self.ks = w.shape[-1]
+        self.cache = None
+
+
+class VideoVAE38_(nn.Module):
+    def __init__(self, dim=160, z_dim=48, dec_dim=256, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                 temperal_downsample=[False, True, True], dropout=0.0):
+        super().__init__()
+        self.dim, self.z_dim, self.dim_mult = dim, z_dim, dim_mult
+        self.temperal_downsample = temperal_downsample
+        self.temperal_upsample = temperal_downsample[::-1]
+        self.encoder = Encoder3d_38(dim, z_dim * 2, dim_mult, num_res_blocks, attn_scales, temperal_downsample, dropout)
+        self.conv1 = CausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.conv2 = CausalConv3d(z_dim, z_dim, 1)
+        self.decoder = Decoder3d_38(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
+        self._conv_states = None
+
+    # ------------------------------------------------------------------ weight preparation
+    def invalidate_packed(self):
+        self._conv_states = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _states(self):
+        if self._conv_states is None:
+            st = {}
+            for mod in [self.conv2] + [m for m in self.decoder.modules() if isinstance(m, (CausalConv3d, nn.Conv2d))]:
+                if mod.weight.shape[-1] == 1 and mod.weight.dim() == 4:
+                    continue        # 1x1 Conv2d of the AttentionBlock: plain GEMMs (F.linear)
+                st[id(mod)] = _ConvState(mod)
+            self._conv_states = st
+        return self._conv_states
+
+    # ------------------------------------------------------------------ building blocks (channels-last)
+    def _conv(self, conv, x, cached=False, residual=None, upsample2x=False, time_interleave=False):
+        st = self._states()[id(conv)]
+        prev = None
+        if cached and st.kt == 3:
+            if st.cache is None:
+                st.cache = torch.zeros((CACHE_T,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            prev = st.cache
+        y = hip.conv3d_cl(x, st.packed, st.bias, st.cout, st.kt, st.ks, prev=prev, residual=residual,
+                          upsample2x=upsample2x, time_interleave=time_interleave)
+        if prev is not None:        # shift the chunk's frames into the ring (wan_video_vae.py:288-297)
+            if x.shape[0] >= CACHE_T:
+                prev.copy_(x[-CACHE_T:])
+            else:
+                prev[0].copy_(prev[1])
+                prev[1].copy_(x[0])
+        return y
+
+    def _res(self, blk, x):
+        r = blk.residual
+        h = x if isinstance(blk.shortcut, nn.Identity) else self._conv(blk.shortcut, x)
+        y = hip.vae_rmsnorm_silu(x, r[0].gamma.view(-1), True)
+        y = self._conv(r[2], y, cached=True)
+        y = hip.vae_rmsnorm_silu(y, r[3].gamma.view(-1), True)
+        return self._conv(r[6], y, cached=True, residual=h)
+
+    def _attn(self, blk, x):
+        t, hh, ww, c = x.shape
+        xn = hip.vae_rmsnorm_silu(x, blk.norm.gamma.view(-1), False)
+        qkv = F.linear(xn.view(t, hh * ww, c), blk.to_qkv.weight.view(3 * c, c), blk.to_qkv.bias)
+        outs = []
+        for f in range(t):          # single head, head_dim = C, per frame (:327-337); GEMMs on hipBLASLt
+            q, k, v = qkv[f, :, :c], qkv[f, :, c:2 * c], qkv[f, :, 2 * c:]
+            scores = torch.matmul(q.float(), k.float().t()).contiguous()
+            outs.append(torch.matmul(hip.softmax_rows(scores, c ** -0.5), v))
+        o = F.linear(torch.stack(outs), blk.proj.weight.view(c, c), blk.proj.bias)
+        return hip.gate_residual(o.view(t, hh, ww, c).contiguous(), x)      # proj(x) + identity
+
+    def _resample_up(self, rs, x, first_chunk):
+        if rs.mode == "upsample3d" and not first_chunk:      # first chunk: 'Rep', no temporal doubling (:125-127)
+            x = self._conv(rs.time_conv, x, cached=True, time_interleave=True)
+        return self._conv(rs.resample[1], x, upsample2x=True)
+
+    def _decoder_chunk(self, x, first_chunk):
+        dec = self.decoder
+        x = self._conv(dec.conv1, x, cached=True)
+        x = self._res(dec.middle[0], x)
+        x = self._attn(dec.middle[1], x)
+        x = self._res(dec.middle[2], x)
+        for up in dec.upsamples:
+            layers = list(up.upsamples)
+            main = x
+            for blk in layers[:3]:
+                main = self._res(blk, main)
+            if up.avg_shortcut is not None:
+                main = self._resample_up(layers[3], main, first_chunk)
+                sc = up.avg_shortcut
+                x = hip.dupup3d_add(x, main, sc.out_channels, sc.factor_t, sc.factor_s, first_chunk)
+            else:
+                x = main
+        x = hip.vae_rmsnorm_silu(x, dec.head[0].gamma.view(-1), True)
+        return self._conv(dec.head[2], x, cached=True)
+
+    def clear_cache(self):
+        if self._conv_states is not None:
+            for st in self._conv_states.values():
+                st.cache = None
+
+    def decode(self, z, scale, clamp=False):
+        """z (1,48,T,h,w) on the HIP device -> (1,3,4T-3,16h,16w) (reference :1326-1351)."""
+        assert z.dim() == 5 and z.shape[0] == 1, "decode one latent at a time (as the reference's tile loop does)"
+        self.clear_cache()
+        mean, inv_std = (s.to(dtype=z.dtype, device=z.device) for s in scale)
+        _, _, T, h, w = z.shape
+        x = hip.vae_latent_to_cl(z[0].contiguous(), mean.contiguous(), inv_std.contiguous())
+        x = self._conv(self.conv2, x)
+        frames = 4 * T - 3
+        video = torch.empty((3, frames, 16 * h, 16 * w), dtype=z.dtype, device=z.device)
+        t0 = 0
+        for i in range(T):
+            out = self._decoder_chunk(x[i:i + 1], first_chunk=(i == 0))
+            hip.vae_unpatchify(out, video, t0, clamp)
+            t0 += out.shape[0]
+        assert t0 == frames
+        self.clear_cache()
+        return video.unsqueeze(0)
+
+    def encode(self, x, scale):
+        raise NotImplementedError("VAE38 encoder is the next hot-path row (SURVEY.md §8f-2); pass first_frame_latents=")
+
+
+class WanVideoVAE38(nn.Module):
+    MEAN = [-0.2289, -0.0052, -0.1323, -0.2339, -0.2799, 0.0174, 0.1838, 0.1557, -0.1382, 0.0542, 0.2813, 0.0891,
+            0.1570, -0.0098, 0.0375, -0.1825, -0.2246, -0.1207, -0.0698, 0.5109, 0.2665, -0.2108, -0.2158, 0.2502,
+            -0.2055, -0.0322, 0.1109, 0.1567, -0.0729, 0.0899, -0.2799, -0.1230, -0.0313, -0.1649, 0.0117, 0.0723,
+            -0.2839, -0.2083, -0.0520, 0.3748, 0.0152, 0.1957, 0.1433, -0.2944, 0.3573, -0.0548, -0.1681, -0.0667]
+    STD = [0.4765, 1.0364, 0.4514, 1.1677, 0.5313, 0.4990, 0.4818, 0.5013, 0.8158, 1.0344, 0.5894, 1.0901,
+           0.6885, 0.6165, 0.8454, 0.4978, 0.5759, 0.3523, 0.7135, 0.6804, 0.5833, 1.4146, 0.8986, 0.5659,
+           0.7069, 0.5338, 0.4889, 0.4917, 0.4069, 0.4999, 0.6866, 0.4093, 0.5709, 0.6065, 0.6415, 0.4944,
+           0.5726, 1.2042, 0.5458, 1.6887, 0.3971, 1.0600, 0.3943, 0.5537, 0.5444, 0.4089, 0.7468, 0.7744]
+
+    def __init__(self, z_dim=48, dim=160, dec_dim=256):
+        super().__init__()
+        self.mean = torch.tensor(self.MEAN)
+        self.std = torch.tensor(self.STD)
+        self.scale = [self.mean, 1.0 / self.std]
+        self.model = VideoVAE38_(z_dim=z_dim, dim=dim, dec_dim=dec_dim).eval().requires_grad_(False)
+        self.upsampling_factor = 16
+        self.z_dim = z_dim
+
+    @staticmethod
+    def tile_tasks(H, W, tile_size, tile_stride):
+        """Tile grid of tiled_decode (:1108-1115)."""
+        (size_h, size_w), (stride_h, stride_w) = tile_size, tile_stride
+        tasks = []
+        for h in range(0, H, stride_h):
+            if h - stride_h >= 0 and h - stride_h + size_h >= H:
+                continue
+            for w in range(0, W, stride_w):
+                if w - stride_w >= 0 and w - stride_w + size_w >= W:
+                    continue
+                tasks.append((h, h + size_h, w, w + size_w))
+        return tasks
+
+    def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
+        """Same tiles, masks and bf16 accumulation as the reference (:1103-1152), but the canvas lives in HBM
+        (654 MB at 704x1280x121) instead of bouncing every tile through host memory."""
+        _, _, T, H, W = hidden_states.shape
+        up = self.upsampling_factor
+        out_T = T * 4 - 3
+        z = hidden_states.to(device)
+        weight = torch.zeros((1, 1, out_T, H * up, W * up), dtype=z.dtype, device=device)
+        values = torch.zeros((1, 3, out_T, H * up, W * up), dtype=z.dtype, device=device)
+        for h, h_, w, w_ in self.tile_tasks(H, W, tile_size, tile_stride):
+            tile = self.model.decode(z[:, :, :, h:h_, w:w_].contiguous(), self.scale)
+            hip.vae_tile_accumulate(tile[0], values[0], weight[0, 0], h * up, w * up,
+                                    (tile_size[0] - tile_stride[0]) * up, (tile_size[1] - tile_stride[1]) * up,
+                                    (h == 0, h_ >= H, w == 0, w_ >= W))
+        hip.vae_tile_finalize(values[0], weight[0, 0])
+        return values
+
+    def single_decode(self, hidden_state, device):
+        return self.model.decode(hidden_state.to(device), self.scale, clamp=True)
+
+    def decode(self, hidden_states, device, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+        """(B,48,T,h,w) -> (B,3,F,H,W) in [-1,1], kept on `device` (:1235-1247)."""
+        videos = []
+        for hidden_state in hidden_states:
+            hidden_state = hidden_state.unsqueeze(0)
+            video = self.tiled_decode(hidden_state, device, tile_size, tile_stride) if tiled \
+                else self.single_decode(hidden_state, device)
+            videos.append(video.squeeze(0))
+        return torch.stack(videos)
+
+    def encode(self, videos, device, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+        return self.model.encode(videos, self.scale)

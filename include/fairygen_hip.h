@@ -1,0 +1,169 @@
+/*
+ * fairygen_hip.h — C ABI of libfairygen_hip.so, the MI355X (gfx950) kernels behind FairyGen's animation
+ * hot path (diffsynth WanVideoPipeline -> Wan2.2-TI2V-5B denoise loop -> Wan2.2 VAE decode).
+ *
+ * The reference is pure Python/PyTorch and has no FFI; each entry point below replaces the ATen op
+ * sequence of one reference call site (cited per function, paths relative to
+ * /root/reference/animation/).  A host binds them with ctypes:
+ * tensor.data_ptr() for buffers, torch.cuda.current_stream().cuda_stream for `stream`.
+ *
+ * Contract (all functions):
+ *   - return 0 on success, a negative FG_E* code on error; fg_last_error() gives a thread-local message;
+ *   - no allocation, no ownership transfer, no host synchronisation: the caller passes every buffer,
+ *     work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the default stream);
+ *   - re-entrant across streams and devices, no mutable global state;
+ *   - all tensors are contiguous row-major device buffers unless a leading dimension (`ld*`, in
+ *     ELEMENTS) is given; bf16 = IEEE bfloat16 bits; pointers must be 16-byte aligned and the channel
+ *     counts multiples of 8 (checked, FG_EINVAL);
+ *   - token tensors are "b s (n d)" exactly like the reference's AttentionModule
+ *     (models/wan_video_dit.py:113-120); VAE activations are channels-last (T,H,W,C) inside the
+ *     decoder, NCTHW only at fg_vae_* boundary kernels.
+ */
+#ifndef FAIRYGEN_HIP_H
+#define FAIRYGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_OK        0
+#define FG_EINVAL   (-1)   /* bad shape / alignment / unsupported size */
+#define FG_ELAUNCH  (-2)   /* hipLaunch failed (message has the HIP error string) */
+
+typedef void* fg_stream_t;   /* hipStream_t */
+
+int         fg_version(void);            /* ABI version, currently 1 */
+const char* fg_last_error(void);         /* thread-local, valid until the next failing call */
+
+/* ------------------------------------------------------------------ DiT token-side kernels (HBM-bound)
+ * "Modulation rows": AdaLN shift/scale/gate vectors live in a small (mod_rows, *, C) table; row r of a
+ * vector starts at ptr + r*mod_ld elements.  mod_rows==1: one row for all tokens (T2V mode);
+ * mod_rows==2: tokens [0,first_rows) use row 0 and the rest row 1 (TI2V mode: first latent frame is at
+ * t=0, pipelines/wan_video.py:1218-1228); mod_rows==rows: one row per token (the reference's literal
+ * (1,N,6,C) layout). */
+
+/* out = bf16(bf16(bf16(LN(x)) * bf16(1+scale)) + shift): nn.LayerNorm(elementwise_affine=False) followed by
+ * modulate(), models/wan_video_dit.py:63-64,205-206,224,227 and Head.forward :261-268. */
+int fg_ln_modulate_bf16(const void* x, const void* shift, const void* scale, void* out,
+                        int64_t rows, int C, float eps,
+                        int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream);
+
+/* out = LN(x)*w + b (norm3, models/wan_video_dit.py:207,226). */
+int fg_ln_affine_bf16(const void* x, const void* w, const void* b, void* out,
+                      int64_t rows, int C, float eps, fg_stream_t stream);
+
+/* out = x + gate*y (GateModule, models/wan_video_dit.py:188-193,225,228) or x + y when gate==NULL (:226).
+ * out may alias x. */
+int fg_gate_residual_bf16(const void* x, const void* y, const void* gate, void* out,
+                          int64_t rows, int C,
+                          int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream);
+
+/* Fused residual + next norm: x_out = x + gate*y (gate may be NULL); then
+ *   mode 0: norm_out = LN(x_out) modulated by (shift, scale) as fg_ln_modulate_bf16,
+ *   mode 1: norm_out = LN(x_out)*w + b (p0 = w, p1 = b; mod_* ignored for the norm).
+ * One pass over HBM instead of two (models/wan_video_dit.py:225-227, and :228 -> next block's :224).
+ * x_out may alias x. */
+int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_out,
+                        const void* p0, const void* p1, void* norm_out, int mode,
+                        int64_t rows, int C, float eps,
+                        int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream);
+
+/* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
+ * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,
+ * CrossAttention.forward :176-177 with cos==sin==NULL).  x has leading dimension ldx (so q/k slices of a
+ * fused QKV projection work), out is (rows, C) contiguous.  cos/sin: fp64 (rows, head_dim/2) tables, the
+ * real/imag parts of the reference's complex128 table (pipelines/wan_video.py:1271-1275); the rotation is
+ * done in fp64 like rope_apply (the kernel is HBM-bound, fp64 VALU is free here). */
+int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight,
+                         const double* cos_tab, const double* sin_tab, void* out,
+                         int64_t rows, int C, int num_heads, float eps, fg_stream_t stream);
+
+/* Elementwise activation, out may alias x.  kind 0: SiLU (time_embedding / time_projection,
+ * models/wan_video_dit.py:312-318); kind 1: GELU(tanh) (ffn / text_embedding, :208-209,307-311). */
+int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t stream);
+
+/* Non-causal softmax attention, head_dim 128: flash_attention()/AttentionModule,
+ * models/wan_video_dit.py:27-60,113-120 (SDPA semantics: softmax(q k^T * scale) v, fp32 accumulate).
+ * q:(B,Nq,H*128) k,v:(B,Nkv,H*128) with leading dimensions ldq/ldk/ldv (elements between token rows) and
+ * batch strides Nq*ldq etc.; out (B,Nq,H*128) contiguous.  bf16 MFMA, fp32 online softmax. */
+int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                     void* out, int B, int64_t Nq, int64_t Nkv, int H, int D, float scale,
+                     fg_stream_t stream);
+
+/* One scheduler step on the latent: pred = nega + cfg*(posi - nega) (pipelines/wan_video.py:302);
+ * out = latents + pred*dsigma (FlowMatchScheduler.step, diffusion/flow_match.py:144-154), each op rounded
+ * to bf16 like the reference's tensor arithmetic; nega==NULL means cfg_scale==1 (pred = posi).
+ * out may alias latents. */
+int fg_cfg_euler_bf16(const void* latents, const void* posi, const void* nega, void* out,
+                      int64_t n, float cfg_scale, float dsigma, fg_stream_t stream);
+
+/* ------------------------------------------------------------------------------- VAE decode kernels
+ * Channels-last activations: (T,H,W,C) bf16.  */
+
+/* RMS_norm over channels (+ optional SiLU): models/wan_video_vae.py:55-70 and the nn.SiLU after it
+ * (:275-279,885): y = silu(bf16(bf16(bf16(x/max(||x||,1e-12)) * sqrt(C)) * gamma)). */
+int fg_vae_rmsnorm_silu_bf16(const void* x, const void* gamma, void* out,
+                             int64_t pixels, int C, int apply_silu, fg_stream_t stream);
+
+/* Repack a Conv3d/Conv2d weight (Cout,Cin,kt,kh,kw) bf16 -> [kt*kh*kw][Cout_pad][Cin_pad] bf16 with
+ * Cin_pad = roundup(Cin,64), Cout_pad = roundup(Cout,128) (zero filled).  fg_conv_packed_bytes gives the size. */
+int64_t fg_conv_packed_bytes(int Cout, int Cin, int kt, int kh, int kw);
+int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int kt, int kh, int kw,
+                             fg_stream_t stream);
+
+/* Causal conv as implicit GEMM on MFMA: CausalConv3d.forward models/wan_video_vae.py:33-52 (kt in {1,3},
+ * kh==kw in {1,3}, stride 1, "same" spatial zero padding, causal time padding) and the Conv2d after
+ * nearest-exact 2x upsampling in Resample38 (:242-251) when upsample2x!=0 (input is (T,H/2,W/2,Cin)).
+ * prev: the layer's feature cache = the previous 2 input frames (2,Hin,Win,Cin), or NULL for zeros
+ * (first chunk / 'Rep').  out (T,H,W,Cout), or with time_interleave!=0 (Resample.forward :153-156,
+ * Cout = 2*Cout2): out (2T,H,W,Cout2) with channel block j of frame t written to frame 2t+j.
+ * residual (same shape as out, or NULL) is added after the bf16 rounding of conv+bias (ResidualBlock
+ * :301). */
+int fg_conv3d_cl_bf16(const void* x, const void* prev, const void* w_packed, const void* bias,
+                      const void* residual, void* out,
+                      int T, int H, int W, int Cin, int Cout, int kt, int ks,
+                      int upsample2x, int time_interleave, fg_stream_t stream);
+
+/* out = main + DupUp3D(x): models/wan_video_vae.py:417-439,510-512.  x (T,H,W,Cin); main/out
+ * (T*ft - drop, H*fs, W*fs, Cout) where drop = ft-1 if first_chunk. */
+int fg_dupup3d_add_bf16(const void* x, const void* main_path, void* out,
+                        int T, int H, int W, int Cin, int Cout, int ft, int fs, int first_chunk,
+                        fg_stream_t stream);
+
+/* Row softmax of fp32 scores * scale -> bf16 probabilities (VAE mid AttentionBlock,
+ * models/wan_video_vae.py:331-336; its two GEMMs stay on hipBLASLt). */
+int fg_softmax_rows_f32_bf16(const float* scores, void* probs, int64_t rows, int64_t cols, float scale,
+                             fg_stream_t stream);
+
+/* Layout boundary: latent NCTHW (C,T,H,W) -> channels-last (T,H,W,C) with the de-normalisation
+ * z/scale[1] + scale[0] of VideoVAE38_.decode (models/wan_video_vae.py:1328-1331): mean/inv_std are bf16 (C). */
+int fg_vae_latent_to_cl_bf16(const void* z, const void* mean, const void* inv_std, void* out,
+                             int C, int T, int H, int W, fg_stream_t stream);
+
+/* Decoder head output (T,H,W,12) channels-last -> unpatchify(…,2) (models/wan_video_vae.py:214-224,1349)
+ * -> frames [t0, t0+T) of a (3,F,2H,2W) NCTHW video; clamp to [-1,1] when do_clamp
+ * (single_decode :1215). */
+int fg_vae_unpatchify_bf16(const void* x, void* video, int T, int H, int W, int F, int t0, int do_clamp,
+                           fg_stream_t stream);
+
+/* Tiled-decode feathering (WanVideoVAE.tiled_decode models/wan_video_vae.py:1124-1149, masks :1081-1100):
+ * values[:, :, y0:y0+th, x0:x0+tw] += tile*mask ; weight[...] += mask, bf16 accumulators like the
+ * reference; mask(y,x) = min(ramp_h(y), ramp_w(x)), ramps of width border_h/border_w on non-bound sides.
+ * values (3,F,Hv,Wv), weight (F,Hv,Wv), tile (3,F,th,tw). bound bits: 1 top, 2 bottom, 4 left, 8 right. */
+int fg_vae_tile_accumulate_bf16(const void* tile, void* values, void* weight,
+                                int F, int Hv, int Wv, int th, int tw, int y0, int x0,
+                                int border_h, int border_w, int bound_bits, fg_stream_t stream);
+
+/* values = clamp(values / weight, -1, 1) (models/wan_video_vae.py:1150-1151). */
+int fg_vae_tile_finalize_bf16(void* values, const void* weight, int F, int Hv, int Wv, fg_stream_t stream);
+
+/* (3,F,H,W) bf16 in [-1,1] -> (F,H,W,3) uint8 by ((x+1)*127.5).clip(0,255) truncation
+ * (BasePipeline.vae_output_to_video, diffusion/base_pipeline.py:128-143). */
+int fg_video_to_uint8(const void* video, void* out_u8, int F, int H, int W, fg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAIRYGEN_HIP_H */

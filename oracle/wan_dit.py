@@ -1,0 +1,175 @@
+"""Oracle: Wan2.2-TI2V-5B DiT forward, functional CPU restatement (test infrastructure only).
+
+Follows ``diffsynth/models/wan_video_dit.py`` and the TI2V branch of ``model_fn_wan_video``
+(``diffsynth/pipelines/wan_video.py:1122-1388``).  Weights come in as a flat state dict using the
+reference's parameter names, so a reference checkpoint, the synthetic checkpoints of
+``fairygen_amd.synthetic`` and the golden fixtures all feed it unchanged.  Every op runs in the
+dtype of the tensors handed in (bf16 in → the reference's bf16 CPU arithmetic, op for op).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- embeddings / tables
+def sinusoid_1d(dim, position):
+    """wan_video_dit.py:67-71 — fp64 sinusoid [cos | sin], cast back to position.dtype."""
+    pos = position.to(torch.float64)
+    inv = torch.pow(10000.0, -torch.arange(dim // 2, dtype=torch.float64).div(dim // 2))
+    ang = torch.outer(pos, inv)
+    return torch.cat([ang.cos(), ang.sin()], dim=1).to(position.dtype)
+
+
+def rope_axis_table(dim, end=1024, theta=10000.0):
+    """wan_video_dit.py:82-88 — complex128 e^{i·pos·theta^(-2j/dim)}, shape (end, dim//2)."""
+    expo = torch.arange(0, dim, 2)[: dim // 2].double() / dim
+    ang = torch.outer(torch.arange(end), 1.0 / theta ** expo)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def rope_table_3d(head_dim, f, h, w):
+    """wan_video_dit.py:74-79 + wan_video.py:1271-1275 — per-token table (f*h*w, 1, head_dim//2).
+
+    head_dim is split frame/height/width as (d - 2*(d//3), d//3, d//3) reals; tokens are frame-major.
+    """
+    df, dh = head_dim - 2 * (head_dim // 3), head_dim // 3
+    tf, th, tw = rope_axis_table(df), rope_axis_table(dh), rope_axis_table(dh)
+    tab = torch.cat([
+        tf[:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+        th[:h].view(1, h, 1, -1).expand(f, h, w, -1),
+        tw[:w].view(1, 1, w, -1).expand(f, h, w, -1),
+    ], dim=-1)
+    return tab.reshape(f * h * w, 1, -1)
+
+
+def rope_apply(x, table, num_heads):
+    """wan_video_dit.py:91-96 — rotate adjacent pairs in fp64, cast back."""
+    b, s, _ = x.shape
+    xc = torch.view_as_complex(x.to(torch.float64).reshape(b, s, num_heads, -1, 2))
+    return torch.view_as_real(xc * table).flatten(2).to(x.dtype)
+
+
+# ----------------------------------------------------------------------------------------- norms
+def rms_norm(x, weight, eps):
+    """wan_video_dit.py:99-110 — fp32 normalise over the FULL last dim, cast, then * weight."""
+    xf = x.float()
+    y = xf * torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)
+    return y.to(x.dtype) * weight
+
+
+def layer_norm(x, eps, weight=None, bias=None):
+    """nn.LayerNorm as used at wan_video_dit.py:205-207,257."""
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def linear(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def attention(q, k, v, num_heads):
+    """wan_video_dit.py:54-59 — the SDPA fallback: softmax(q k^T / sqrt(d)) v, no mask."""
+    b, sq, c = q.shape
+    d = c // num_heads
+    qh = q.view(b, sq, num_heads, d).transpose(1, 2)
+    kh = k.view(b, k.shape[1], num_heads, d).transpose(1, 2)
+    vh = v.view(b, v.shape[1], num_heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(b, sq, c)
+
+
+# --------------------------------------------------------------------------------------- modules
+def self_attention(sd, p, x, table, num_heads, eps):
+    """wan_video_dit.py:139-146."""
+    q = rms_norm(linear(sd, p + ".q", x), sd[p + ".norm_q.weight"], eps)
+    k = rms_norm(linear(sd, p + ".k", x), sd[p + ".norm_k.weight"], eps)
+    v = linear(sd, p + ".v", x)
+    q = rope_apply(q, table, num_heads)
+    k = rope_apply(k, table, num_heads)
+    return linear(sd, p + ".o", attention(q, k, v, num_heads))
+
+
+def cross_attention(sd, p, x, ctx, num_heads, eps):
+    """wan_video_dit.py:170-185, has_image_input=False branch."""
+    q = rms_norm(linear(sd, p + ".q", x), sd[p + ".norm_q.weight"], eps)
+    k = rms_norm(linear(sd, p + ".k", ctx), sd[p + ".norm_k.weight"], eps)
+    v = linear(sd, p + ".v", ctx)
+    return linear(sd, p + ".o", attention(q, k, v, num_heads))
+
+
+def dit_block(sd, p, x, ctx, t_mod, table, num_heads, eps):
+    """wan_video_dit.py:213-229 — AdaLN-Zero block; t_mod is (B,6,C) or per-token (B,N,6,C)."""
+    per_token = t_mod.dim() == 4
+    mod = sd[p + ".modulation"].to(dtype=t_mod.dtype) + t_mod
+    parts = mod.chunk(6, dim=2 if per_token else 1)
+    if per_token:
+        parts = [u.squeeze(2) for u in parts]
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = parts
+    h = layer_norm(x, eps) * (1 + scale_msa) + shift_msa
+    x = x + gate_msa * self_attention(sd, p + ".self_attn", h, table, num_heads, eps)
+    x = x + cross_attention(sd, p + ".cross_attn",
+                            layer_norm(x, eps, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"]),
+                            ctx, num_heads, eps)
+    h = layer_norm(x, eps) * (1 + scale_mlp) + shift_mlp
+    h = linear(sd, p + ".ffn.2", F.gelu(linear(sd, p + ".ffn.0", h), approximate="tanh"))
+    return x + gate_mlp * h
+
+
+def head(sd, x, t, eps):
+    """wan_video_dit.py:261-268 — t is (B,N,C) per token (TI2V) or (B,C)."""
+    m = sd["head.modulation"].to(dtype=t.dtype)
+    if t.dim() == 3:
+        shift, scale = (m.unsqueeze(0) + t.unsqueeze(2)).chunk(2, dim=2)
+        y = layer_norm(x, eps) * (1 + scale.squeeze(2)) + shift.squeeze(2)
+    else:
+        shift, scale = (m + t).chunk(2, dim=1)
+        y = layer_norm(x, eps) * (1 + scale) + shift
+    return linear(sd, "head.head", y)
+
+
+def patchify_tokens(sd, latents, patch):
+    """wan_video_dit.py:338-339 + wan_video.py:1260-1261 — Conv3d k=s=patch, then frame-major tokens."""
+    x = F.conv3d(latents, sd["patch_embedding.weight"], sd["patch_embedding.bias"], stride=tuple(patch))
+    f, h, w = x.shape[2:]
+    return x.flatten(2).transpose(1, 2).contiguous(), (f, h, w)
+
+
+def unpatchify(x, grid, patch, out_dim):
+    """wan_video_dit.py:346-351 — 'b (f h w) (x y z c) -> b c (f x) (h y) (w z)'."""
+    f, h, w = grid
+    px, py, pz = patch
+    b = x.shape[0]
+    x = x.view(b, f, h, w, px, py, pz, out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return x.reshape(b, out_dim, f * px, h * py, w * pz)
+
+
+def model_fn(sd, cfg, latents, timestep, context, fuse_vae_embedding_in_latents=True, num_blocks=None):
+    """One DiT forward = model_fn_wan_video (wan_video.py:1217-1231,1236,1253-1275,1329-1362,1378,1387).
+
+    cfg: dict with dim, num_heads, eps, patch_size, freq_dim, out_dim, seperated_timestep.
+    """
+    dim, nh, eps, patch = cfg["dim"], cfg["num_heads"], cfg["eps"], tuple(cfg["patch_size"])
+
+    def time_embedding(e):
+        return linear(sd, "time_embedding.2", F.silu(linear(sd, "time_embedding.0", e)))
+
+    if cfg.get("seperated_timestep", False) and fuse_vae_embedding_in_latents:
+        per_frame = latents.shape[3] * latents.shape[4] // 4
+        ts = torch.cat([
+            torch.zeros((1, per_frame), dtype=latents.dtype),
+            torch.ones((latents.shape[2] - 1, per_frame), dtype=latents.dtype) * timestep,
+        ]).flatten()
+        t = time_embedding(sinusoid_1d(cfg["freq_dim"], ts).unsqueeze(0))
+        t_mod = linear(sd, "time_projection.1", F.silu(t)).unflatten(2, (6, dim))
+    else:
+        t = time_embedding(sinusoid_1d(cfg["freq_dim"], timestep))
+        t_mod = linear(sd, "time_projection.1", F.silu(t)).unflatten(1, (6, dim))
+
+    ctx = linear(sd, "text_embedding.2", F.gelu(linear(sd, "text_embedding.0", context), approximate="tanh"))
+    x, (f, h, w) = patchify_tokens(sd, latents, patch)
+    table = rope_table_3d(dim // nh, f, h, w)
+    nblocks = cfg["num_layers"] if num_blocks is None else num_blocks
+    for i in range(nblocks):
+        x = dit_block(sd, f"blocks.{i}", x, ctx, t_mod, table, nh, eps)
+    x = head(sd, x, t, eps)
+    return unpatchify(x, (f, h, w), patch, cfg["out_dim"])
