@@ -25,8 +25,8 @@ def sinusoidal_embedding_1d(dim, position):
 
 def precompute_freqs_cis(dim, end=1024, theta=10000.0):
     """complex128 rotation table of one axis (reference :82-88)."""
-    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].double() / dim))
-    freqs = torch.outer(torch.arange(end), freqs)
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, device="cpu")[: dim // 2].double() / dim))
+    freqs = torch.outer(torch.arange(end, device="cpu"), freqs)      # explicit cpu: models are built under device("meta")
     return torch.polar(torch.ones_like(freqs), freqs)
 
 

@@ -306,8 +306,8 @@ class WanVideoVAE38(nn.Module):
 
     def __init__(self, z_dim=48, dim=160, dec_dim=256):
         super().__init__()
-        self.mean = torch.tensor(self.MEAN)
-        self.std = torch.tensor(self.STD)
+        self.mean = torch.tensor(self.MEAN, device="cpu")     # explicit cpu: models are built under device("meta")
+        self.std = torch.tensor(self.STD, device="cpu")
         self.scale = [self.mean, 1.0 / self.std]
         self.model = VideoVAE38_(z_dim=z_dim, dim=dim, dec_dim=dec_dim).eval().requires_grad_(False)
         self.upsampling_factor = 16

@@ -1,0 +1,268 @@
+"""GPU parity: every HIP kernel, called through the C ABI (fairygen_amd.hip), against the CPU oracle.
+
+Tolerances (floating point; stated per test):
+  * elementwise kernels reproduce the reference's bf16 rounding points, so they must match the oracle's bf16
+    result to <= 1 bf16 ulp (reduction order inside a LayerNorm/RMSNorm row may flip a rounding);
+  * MFMA kernels (attention, conv): error vs the oracle's fp32 result <= 2x the error of the oracle's own
+    bf16 result vs fp32 on the same inputs, plus a small floor (SURVEY.md §8d "parity tolerance").
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import seeded
+from oracle import wan_dit, wan_vae
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from fairygen_amd import hip as h
+    h.load()
+    assert torch.cuda.is_available()
+    return h
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def ulp_diff(a, b):
+    """max difference in bf16 ulps (as int16 bit patterns of same-sign values) + max abs."""
+    a, b = a.float().cpu(), b.float().cpu()
+    return (a - b).abs().max().item()
+
+
+def assert_close_bf16(got, want, rel_ulps=1.0, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    tol = rel_ulps * (want.abs().clamp_min(1e-3) * 2.0 ** -7)       # 1 bf16 ulp ~ 2^-7 relative (upper bound)
+    bad = ((got - want).abs() > tol)
+    assert not bad.any(), f"{what}: {bad.sum().item()} / {bad.numel()} beyond {rel_ulps} ulp; max abs {(got - want).abs().max().item()}"
+
+
+# ------------------------------------------------------------------------------------------ DiT elementwise
+@pytest.mark.parametrize("rows,C,mod_rows", [(37, 3072, 2), (5, 256, 1), (130, 3072, 130), (64, 1536, 2)])
+def test_ln_modulate(hip, rows, C, mod_rows):
+    x = seeded((1, rows, C), 1)
+    table = seeded((mod_rows, 6, C), 2, scale=0.5)
+    first = rows // 3
+    mod = hip.ModTable(dev(table), first)
+    got = hip.ln_modulate(dev(x), mod, 0, 1, 1e-6)
+    idx = torch.zeros(rows, dtype=torch.long) if mod_rows == 1 else (
+        (torch.arange(rows) >= first).long() if mod_rows == 2 else torch.arange(rows))
+    shift, scale = table[idx, 0].unsqueeze(0), table[idx, 1].unsqueeze(0)
+    want = wan_dit.layer_norm(x, 1e-6) * (1 + scale) + shift
+    assert_close_bf16(got, want, 1.0, "ln_modulate")
+
+
+def test_ln_affine_and_gate_residual(hip):
+    rows, C = 77, 3072
+    x, y = seeded((1, rows, C), 3), seeded((1, rows, C), 4)
+    w, b = 1 + 0.1 * seeded((C,), 5), 0.1 * seeded((C,), 6)
+    w, b = w.to(torch.bfloat16), b.to(torch.bfloat16)
+    assert_close_bf16(hip.ln_affine(dev(x), dev(w), dev(b), 1e-6), wan_dit.layer_norm(x, 1e-6, w, b), 1.0, "ln_affine")
+    table = seeded((2, 6, C), 7)
+    mod = hip.ModTable(dev(table), 30)
+    idx = (torch.arange(rows) >= 30).long()
+    got = hip.gate_residual(dev(x), dev(y), mod, 2)
+    assert torch.equal(got.cpu(), x + table[idx, 2].unsqueeze(0) * y)          # pure elementwise: bit exact
+    assert torch.equal(hip.gate_residual(dev(x), dev(y)).cpu(), x + y)
+
+
+def test_fused_residual_norms(hip):
+    rows, C = 45, 3072
+    x, y = seeded((1, rows, C), 8), seeded((1, rows, C), 9)
+    table, table2 = seeded((2, 6, C), 10, scale=0.5), seeded((2, 6, C), 11, scale=0.5)
+    idx = (torch.arange(rows) >= 20).long()
+    mod, mod2 = hip.ModTable(dev(table), 20), hip.ModTable(dev(table2), 20)
+    x1 = x + table[idx, 5].unsqueeze(0) * y
+    xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, 5, 0, 1, 1e-6, norm_mod=mod2)
+    assert torch.equal(xo.cpu(), x1)
+    assert_close_bf16(no, wan_dit.layer_norm(x1, 1e-6) * (1 + table2[idx, 1].unsqueeze(0)) + table2[idx, 0].unsqueeze(0), 1.0, "res+modulate")
+    xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, None, 3, 4, 1e-6)
+    assert torch.equal(xo.cpu(), x + y)
+    w, b = (1 + 0.1 * seeded((C,), 5)).to(torch.bfloat16), (0.1 * seeded((C,), 6)).to(torch.bfloat16)
+    xo, no = hip.residual_ln_affine(dev(x), dev(y), dev(w), dev(b), 1e-6, mod, 2)
+    x2 = x + table[idx, 2].unsqueeze(0) * y
+    assert torch.equal(xo.cpu(), x2)
+    assert_close_bf16(no, wan_dit.layer_norm(x2, 1e-6, w, b), 1.0, "res+affine")
+
+
+@pytest.mark.parametrize("heads,C,grid", [(24, 3072, (2, 3, 5)), (2, 256, (3, 4, 4))])
+def test_rmsnorm_rope(hip, heads, C, grid):
+    f, h, w_ = grid
+    n = f * h * w_
+    wide = seeded((1, n, 3 * C), 12)                     # q slice of a fused QKV buffer (ld = 3C)
+    wt = (1 + 0.1 * seeded((C,), 13)).to(torch.bfloat16)
+    table = wan_dit.rope_table_3d(C // heads, f, h, w_)
+    cos, sin = table.real.reshape(n, -1).contiguous(), table.imag.reshape(n, -1).contiguous()
+    xq = wide[..., C:2 * C]
+    want = wan_dit.rope_apply(wan_dit.rms_norm(xq, wt, 1e-6), table, heads)
+    got = hip.rmsnorm_rope(dev(wide)[..., C:2 * C], dev(wt), heads, 1e-6, dev(cos), dev(sin))
+    assert_close_bf16(got, want, 1.0, "rmsnorm+rope")
+    got = hip.rmsnorm_rope(dev(wide)[..., :C], dev(wt), heads, 1e-6)
+    assert_close_bf16(got, wan_dit.rms_norm(wide[..., :C], wt, 1e-6), 1.0, "rmsnorm")
+
+
+def test_activations_and_cfg_euler(hip):
+    x = seeded((3, 1000, 8), 14, scale=3.0)
+    assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu")
+    assert_close_bf16(hip.activation(dev(x).clone(), "gelu_tanh"), F.gelu(x, approximate="tanh"), 1.0, "gelu")
+    lat, p, n_ = seeded((1, 48, 3, 8, 8), 15), seeded((1, 48, 3, 8, 8), 16), seeded((1, 48, 3, 8, 8), 17)
+    sig, _ = opipe.wan_sigmas(4)
+    for i in range(4):
+        pred = n_ + 5.0 * (p - n_)
+        want = opipe.euler_step(pred, i, lat, sig)
+        ds = float((0 if i == 3 else sig[i + 1]) - sig[i])
+        assert torch.equal(hip.cfg_euler(dev(lat), dev(p), dev(n_), 5.0, ds).cpu(), want), f"cfg+euler step {i}"
+    want = opipe.euler_step(p, 1, lat, sig)
+    assert torch.equal(hip.cfg_euler(dev(lat), dev(p), None, 1.0, float(sig[2] - sig[1])).cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_case(hip, nq, nkv, heads, seed, scale_q=1.0):
+    c = heads * 128
+    q, k, v = seeded((1, nq, c), seed, scale=scale_q), seeded((1, nkv, c), seed + 1), seeded((1, nkv, c), seed + 2)
+    ref32 = wan_dit.attention(q.float(), k.float(), v.float(), heads)
+    ref16 = wan_dit.attention(q, k, v, heads).float()
+    got = hip.attention(dev(q), dev(k), dev(v), heads).float().cpu()
+    err_ref = (ref16 - ref32).abs().max().item()
+    err = (got - ref32).abs().max().item()
+    assert err <= 2 * err_ref + 2e-3, f"attention nq={nq} nkv={nkv}: err {err} vs reference-bf16 err {err_ref}"
+    return err, err_ref
+
+
+@pytest.mark.parametrize("nq,nkv,heads", [(256, 64, 1), (300, 77, 2), (513, 512, 3), (64, 1000, 2), (1560, 1560, 2), (31, 5, 1)])
+def test_attention_shapes(hip, nq, nkv, heads):
+    _attn_case(hip, nq, nkv, heads, 20)
+
+
+def test_attention_peaked_softmax(hip):
+    # large-magnitude queries: near one-hot softmax rows exercise the running-max rescale path
+    _attn_case(hip, 200, 333, 2, 30, scale_q=8.0)
+
+
+def test_attention_strided_inputs(hip):
+    heads, n = 2, 150
+    c = heads * 128
+    qkv = seeded((1, n, 3 * c), 40)
+    q = qkv[..., :c].contiguous()
+    want = wan_dit.attention(q.float(), qkv[..., c:2 * c].float(), qkv[..., 2 * c:].float(), heads)
+    d = dev(qkv)
+    got = hip.attention(dev(q), d[..., c:2 * c], d[..., 2 * c:], heads).float().cpu()
+    assert (got - want).abs().max().item() < 2e-2
+
+
+def test_attention_rejects_cpu_and_bad_head_dim(hip):
+    q = seeded((1, 8, 256), 1)
+    with pytest.raises(hip.HipLibraryError):
+        hip.attention(q, q, q, 2)                       # CPU tensors: no fallback
+    with pytest.raises(hip.HipLibraryError):
+        hip.attention(dev(q), dev(q), dev(q), 4)        # head_dim 64 unsupported
+
+
+# ------------------------------------------------------------------------------------------------ VAE kernels
+def _cl(x):      # (1,C,T,H,W) -> (T,H,W,C)
+    return x[0].permute(1, 2, 3, 0).contiguous()
+
+
+def _ncthw(x):   # (T,H,W,C) -> (1,C,T,H,W)
+    return x.permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,kt,ks,T,H,W,cache", [
+    (48, 64, 3, 3, 1, 6, 10, False), (64, 128, 3, 3, 2, 9, 7, True), (128, 256, 3, 1, 1, 5, 6, True),
+    (96, 48, 1, 1, 3, 4, 4, False), (256, 12, 3, 3, 4, 8, 8, True), (1024, 1024, 3, 3, 1, 4, 6, True)])
+def test_conv3d_cl(hip, cin, cout, kt, ks, T, H, W, cache):
+    x = seeded((1, cin, T, H, W), 50)
+    w = seeded((cout, cin, kt, ks, ks), 51, scale=(cin * kt * ks * ks) ** -0.5)
+    b = seeded((cout,), 52, scale=0.1)
+    prev = seeded((1, cin, 2, H, W), 53) if cache else None
+    sd = {"c.weight": w, "c.bias": b}
+    ref16 = wan_vae.causal_conv3d(sd, "c", x, prev).float()
+    sd32 = {k: v.float() for k, v in sd.items()}
+    ref32 = wan_vae.causal_conv3d(sd32, "c", x.float(), None if prev is None else prev.float())
+    packed = hip.conv_pack_weight(dev(w))
+    got = hip.conv3d_cl(dev(_cl(x)), packed, dev(b), cout, kt, ks, prev=None if prev is None else dev(_cl(prev)))
+    got = _ncthw(got.cpu()).float()
+    err_ref, err = (ref16 - ref32).abs().max().item(), (got - ref32).abs().max().item()
+    assert err <= 2 * err_ref + 1e-3, f"conv err {err} vs reference-bf16 err {err_ref}"
+
+
+def test_conv_upsample_interleave_residual(hip):
+    c = 64
+    x = seeded((1, c, 2, 5, 6), 60)
+    w2 = seeded((c, c, 3, 3), 61, scale=(c * 9) ** -0.5)
+    b2 = seeded((c,), 62, scale=0.1)
+    res = seeded((1, c, 2, 10, 12), 63)
+    y = F.interpolate(x[0].permute(1, 0, 2, 3).float(), scale_factor=(2.0, 2.0), mode="nearest-exact").to(torch.bfloat16)
+    want = F.conv2d(y, w2, b2, padding=1).permute(1, 0, 2, 3).unsqueeze(0) + res
+    got = hip.conv3d_cl(dev(_cl(x)), hip.conv_pack_weight(dev(w2)), dev(b2), c, 1, 3, upsample2x=True, residual=dev(_cl(res)))
+    assert (_ncthw(got.cpu()).float() - want.float()).abs().max().item() < 3e-2
+    # time_conv + channel->time interleave (Resample.forward :147-156)
+    wt = seeded((2 * c, c, 3, 1, 1), 64, scale=(c * 3) ** -0.5)
+    bt = seeded((2 * c,), 65, scale=0.1)
+    prev = seeded((1, c, 2, 5, 6), 66)
+    t = wan_vae.causal_conv3d({"c.weight": wt, "c.bias": bt}, "c", x, prev)
+    t = t.reshape(1, 2, c, 2, 5, 6)
+    want = torch.stack((t[:, 0], t[:, 1]), 3).reshape(1, c, 4, 5, 6)
+    got = hip.conv3d_cl(dev(_cl(x)), hip.conv_pack_weight(dev(wt)), dev(bt), 2 * c, 3, 1, prev=dev(_cl(prev)), time_interleave=True)
+    assert (_ncthw(got.cpu()).float() - want.float()).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("C,silu", [(1024, True), (256, True), (32, False), (512, True)])
+def test_vae_rmsnorm_silu(hip, C, silu):
+    x = seeded((1, C, 2, 5, 7), 70, scale=2.0)
+    g = (1 + 0.1 * seeded((C, 1, 1, 1), 71)).to(torch.bfloat16)
+    want = wan_vae.rms_norm_c({"n.gamma": g}, "n", x)
+    want = F.silu(want) if silu else want
+    got = hip.vae_rmsnorm_silu(dev(_cl(x)), dev(g.view(-1)), silu)
+    assert_close_bf16(_ncthw(got.cpu()), want, 1.0, "vae rmsnorm")
+
+
+@pytest.mark.parametrize("cin,cout,ft,fs,first", [(64, 64, 2, 2, True), (64, 64, 2, 2, False), (64, 32, 1, 2, False), (128, 64, 1, 2, True)])
+def test_dupup3d_add(hip, cin, cout, ft, fs, first):
+    x = seeded((1, cin, 2, 3, 4), 80)
+    sc = wan_vae.dup_up3d(x, cout, ft, fs, first)
+    main = seeded(tuple(sc.shape), 81)
+    got = hip.dupup3d_add(dev(_cl(x)), dev(_cl(main)), cout, ft, fs, first)
+    assert torch.equal(_ncthw(got.cpu()), main + sc)
+
+
+def test_softmax_latent_unpatchify_uint8(hip):
+    s = seeded((37, 301), 90, torch.float32, scale=20.0)
+    want = torch.softmax(s * 0.25, dim=-1)
+    assert (hip.softmax_rows(dev(s), 0.25).float().cpu() - want).abs().max().item() < 4e-3
+    z = seeded((1, 48, 2, 3, 5), 91)
+    mean, inv_std = torch.tensor(wan_vae.VAE38_MEAN).to(torch.bfloat16), (1.0 / torch.tensor(wan_vae.VAE38_STD)).to(torch.bfloat16)
+    want = z / inv_std.view(1, 48, 1, 1, 1) + mean.view(1, 48, 1, 1, 1)
+    assert torch.equal(_ncthw(hip.vae_latent_to_cl(dev(z[0].contiguous()), dev(mean), dev(inv_std)).cpu()), want)
+    x = seeded((1, 12, 3, 4, 5), 92, scale=0.8)
+    video = torch.zeros((3, 5, 8, 10), dtype=torch.bfloat16, device="cuda")
+    hip.vae_unpatchify(dev(_cl(x)), video, 2, True)
+    assert torch.equal(video[:, 2:5].cpu(), wan_vae.unpatchify2(x)[0].clamp(-1, 1))
+    vid = seeded((3, 2, 8, 8), 93, scale=0.7).clamp(-1.2, 1.2)
+    assert torch.equal(hip.video_to_uint8(dev(vid)).cpu(), opipe.video_to_uint8(vid))
+
+
+def test_tile_blend(hip):
+    H, W, up, T = 5, 7, 2, 2
+    F_ = 4 * T - 3
+    tile_size, tile_stride = (3, 4), (2, 3)
+    values = torch.zeros((3, F_, H * up, W * up), dtype=torch.bfloat16)
+    weight = torch.zeros((F_, H * up, W * up), dtype=torch.bfloat16)
+    dv, dw = dev(values), dev(weight)
+    for i, (h, h_, w, w_) in enumerate(wan_vae.tile_tasks(H, W, tile_size, tile_stride)):
+        th, tw = (min(h_, H) - h) * up, (min(w_, W) - w) * up
+        tile = seeded((3, F_, th, tw), 100 + i)
+        bounds = (h == 0, h_ >= H, w == 0, w_ >= W)
+        border = ((tile_size[0] - tile_stride[0]) * up, (tile_size[1] - tile_stride[1]) * up)
+        m = wan_vae.tile_mask(th, tw, bounds, border).to(torch.bfloat16)[0, 0]
+        values[:, :, h * up:h * up + th, w * up:w * up + tw] += tile * m
+        weight[:, h * up:h * up + th, w * up:w * up + tw] += m[0]
+        hip.vae_tile_accumulate(dev(tile), dv, dw, h * up, w * up, border[0], border[1], bounds)
+    assert torch.equal(dv.cpu(), values) and torch.equal(dw.cpu(), weight)
+    hip.vae_tile_finalize(dv, dw)
+    assert torch.equal(dv.cpu(), (values / weight).clamp_(-1, 1))

@@ -1,0 +1,98 @@
+"""Pins the CPU oracle against vectors produced by the reference's own code (oracle/gen_golden.py).
+
+Same dtype + same op order => the bf16 comparisons are bit-exact; the two places where the oracle's
+formulation differs from the reference's module code by a mathematically equal rewrite are given a stated
+tolerance of one bf16 ulp.
+"""
+import torch
+
+from conftest import seeded
+from oracle import pipeline as opipe
+from oracle import wan_dit, wan_vae
+from fairygen_amd import synthetic
+
+
+def test_dit_primitives(golden):
+    g = golden("dit_primitives.safetensors")
+    x = seeded((1, 24, 256), 11)
+    table = wan_dit.rope_table_3d(128, 2, 3, 4)
+    assert torch.equal(table.real.contiguous(), g["rope_table_real"]) and torch.equal(table.imag.contiguous(), g["rope_table_imag"])
+    assert torch.equal(wan_dit.rope_apply(x, table, 2), g["rope_out"])
+    assert torch.equal(wan_dit.sinusoid_1d(256, torch.tensor([0.0, 996.0, 92.5], dtype=torch.bfloat16)), g["sinusoid_bf16"])
+    assert torch.equal(wan_dit.sinusoid_1d(256, torch.tensor([0.0, 995.9, 92.59])), g["sinusoid_f32"])
+    w = (1 + 0.1 * seeded((256,), 12, torch.float32)).to(torch.bfloat16)
+    assert torch.equal(wan_dit.rms_norm(x, w, 1e-6), g["rmsnorm_out"])
+    mod = wan_dit.layer_norm(x, 1e-6) * (1 + seeded((1, 1, 256), 14)) + seeded((1, 1, 256), 13)
+    assert torch.equal(mod, g["modulate_out"])
+    q, k, v = seeded((1, 80, 256), 15), seeded((1, 50, 256), 16), seeded((1, 50, 256), 17)
+    assert torch.equal(wan_dit.attention(q, k, v, 2), g["attn_out_bf16"])
+    assert torch.allclose(wan_dit.attention(q.float(), k.float(), v.float(), 2), g["attn_out_f32"], atol=1e-6)
+    assert torch.equal(x + seeded((1, 1, 256), 18) * seeded((1, 24, 256), 19), g["gate_out"])
+
+
+def _tiny_inputs():
+    lat = seeded((1, 48, 3, 8, 8), 1)
+    ctx_p = seeded((1, 16, 128), 2); ctx_p[:, 10:] = 0
+    ctx_n = seeded((1, 16, 128), 3); ctx_n[:, 12:] = 0
+    return lat, ctx_p, ctx_n, seeded((1, 48, 1, 8, 8), 4), torch.tensor([995.9]).to(torch.bfloat16)
+
+
+def test_dit_tiny_forward_and_loop(golden):
+    g = golden("dit_tiny.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    lat, ctx_p, ctx_n, z0, ts = _tiny_inputs()
+    assert torch.equal(wan_dit.model_fn(sd, cfg, lat, ts, ctx_p, True), g["ti2v_bf16"])
+    assert torch.equal(wan_dit.model_fn(sd, cfg, lat, ts, ctx_p, False), g["t2v_bf16"])
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert torch.allclose(wan_dit.model_fn(sd32, cfg, lat.float(), ts.float(), ctx_p.float(), True), g["ti2v_f32"], atol=2e-5, rtol=1e-5)
+    rec = []
+    opipe.denoise_loop(sd, cfg, lat, ctx_p, ctx_n, 4, 5.0, 5.0, z0, record=rec)
+    for i, r in enumerate(rec):
+        assert torch.equal(r, g[f"loop_step{i}"]), f"loop step {i}"
+
+
+def test_scheduler(golden):
+    g = golden("scheduler.safetensors")
+    for n in (4, 30, 50):
+        s, t = opipe.wan_sigmas(n, shift=5.0)
+        assert torch.equal(s, g[f"sigmas_{n}"]) and torch.equal(t, g[f"timesteps_{n}"])
+    s, _ = opipe.wan_sigmas(4, shift=5.0)
+    xs, vs = seeded((1, 4, 2, 3, 3), 21), seeded((1, 4, 2, 3, 3), 22)
+    for i in range(4):
+        assert torch.equal(opipe.euler_step(vs, i, xs, s), g[f"step_{i}"])
+
+
+def test_lora_fuse_and_merge(golden):
+    g = golden("lora.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    shapes = synthetic.dit_shapes(cfg)
+    sd = synthetic.random_state_dict(shapes, seed=1234)
+    lora = synthetic.random_lora(shapes, rank=4, seed=4321)
+    assert opipe.fuse_lora(sd, lora, alpha=0.5) == 20
+    for k in ("blocks.0.self_attn.q.weight", "blocks.1.cross_attn.v.weight", "blocks.1.ffn.2.weight", "blocks.0.ffn.0.weight",
+              "blocks.0.self_attn.q.bias"):
+        assert torch.equal(sd[k], g[k]), k
+    stage2 = {k.replace(".lora_B.default.weight", ".lora_B2.weight"): seeded(v.shape, 77 + i, scale=0.02)
+              for i, (k, v) in enumerate(sorted(lora.items())) if ".lora_B." in k}
+    merged = opipe.merge_stage_loras(lora, stage2)
+    assert len(merged) == int(g["merged_num_keys"])
+    assert torch.equal(merged["blocks.0.self_attn.q.lora_B.default.weight"], g["merged.blocks.0.self_attn.q.lora_B"])
+    assert torch.equal(merged["blocks.1.ffn.0.lora_A.default.weight"], g["merged.blocks.1.ffn.0.lora_A"])
+
+
+def test_vae_tiny_decode(golden):
+    g = golden("vae_tiny.safetensors")
+    sd = synthetic.random_state_dict(synthetic.vae_shapes(dec_dim=32, dim=32), seed=1234)
+    z = seeded((1, 48, 3, 4, 6), 31)
+    assert torch.equal(wan_vae.vae_decode(sd, z, tiled=False), g["decode_bf16"])
+    assert torch.equal(wan_vae.vae_decode(sd, z, tiled=True, tile_size=(3, 4), tile_stride=(2, 2)), g["tiled_bf16"])
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert torch.allclose(wan_vae.vae_decode(sd32, z.float(), tiled=False), g["decode_f32"], atol=1e-5, rtol=1e-5)
+
+
+def test_pixels_and_noise(golden):
+    g = golden("pixels.safetensors")
+    assert torch.equal(opipe.generate_noise((1, 48, 2, 4, 4), 1), g["noise_seed1"])
+    vid = seeded((1, 3, 2, 8, 8), 41, scale=0.7).clamp(-1.2, 1.2)
+    assert torch.equal(opipe.video_to_uint8(vid[0]), g["uint8_frames"])
