@@ -1,0 +1,253 @@
+"""bench.py — FairyGen animation hot path on MI355X: decoded frames/sec and sec/clip.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric / configs[2]): Wan2.2-TI2V-5B, 704x1280x121, TI2V (first latent frame pinned),
+CFG 5.0, sigma shift 5.0, merged rank-32 motion LoRA fused at load, random-init bf16 weights with the reference's
+key/shape set, synthetic context tensors.  A "step" is one denoise step of the clip =
+forward(+), forward(-), CFG combine + Euler update, first-frame re-pin.  The timed region is the WHOLE clip for
+num_inference_steps = K: K steps followed by the VAE decode to (1,3,121,704,1280) (tiled exactly like
+inference.py's tiled=True unless --untiled), inputs resident in HBM; value = frames / t_clip.  Default K = 50
+is the headline configuration; ms_per_step = t_clip / K (decode amortised).
+N > 1 ("strong" scaling: one clip, total work fixed): tokens sharded by latent-temporal ranges with an RCCL
+K/V all-gather per self-attention layer; VAE tiles are decoded round-robin over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def seeded(shape, seed, dtype=torch.bfloat16):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32).to(dtype)
+
+
+def build_pipeline(args, device):
+    from fairygen_amd import synthetic
+    from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
+    from fairygen_amd.wan_video import WanVideoPipeline
+    from fairygen_amd.wan_video_dit import WanModel
+    from fairygen_amd.wan_video_vae import WanVideoVAE38
+
+    cfg = dict(TI2V_5B_DIT_KWARGS)
+    if args.layers:
+        cfg["num_layers"] = args.layers           # debugging only; the JSON line then says so
+    pipe = WanVideoPipeline(device=device, torch_dtype=torch.bfloat16)
+    shapes = synthetic.dit_shapes(cfg)
+    with torch.device("meta"):
+        dit = WanModel(**cfg)
+    dit.load_state_dict(synthetic.random_state_dict(shapes, seed=1234, device=device), assign=True)
+    pipe.dit = dit.to(device=device, dtype=torch.bfloat16).eval()
+    if not args.no_lora:
+        lora = synthetic.random_lora(shapes, rank=32, seed=4321)
+        pipe.load_lora(pipe.dit, state_dict=lora, alpha=1)
+    with torch.device("meta"):
+        vae = WanVideoVAE38()
+    vae.load_state_dict(synthetic.random_state_dict(synthetic.vae_shapes(), seed=1234, device=device, only_prefix="model.dec")
+                        | synthetic.random_state_dict({k: v for k, v in synthetic.vae_shapes().items() if not k.startswith("model.dec")},
+                                                      seed=1, device=device), assign=True)
+    pipe.vae = vae.to(device=device, dtype=torch.bfloat16).eval()
+    pipe.height_division_factor = pipe.width_division_factor = 32
+    return pipe, cfg
+
+
+class KernelTimer:
+    """HIP events (on torch's current stream = the stream the kernels are launched on) around every
+    fg_attn_fwd_bf16 launch of the timed region."""
+
+    def __init__(self):
+        self.records = []      # (nq, nkv, heads, start, end)
+
+    def install(self):
+        from fairygen_amd import hip
+        self._orig = hip.attention
+        timer = self
+
+        def timed_attention(q, k, v, num_heads, out=None):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig(q, k, v, num_heads, out)
+            e.record()
+            timer.records.append((q.shape[1], k.shape[1], num_heads, s, e))
+            return r
+        hip.attention = timed_attention
+
+    def uninstall(self):
+        from fairygen_amd import hip
+        hip.attention = self._orig
+
+    def self_attention_stats(self):
+        durs, flops = [], 0.0
+        for nq, nkv, h, s, e in self.records:
+            if nkv > 1024:         # self-attention launches (cross-attention has Nkv = 512)
+                durs.append(s.elapsed_time(e) * 1e-3)
+                flops = 4.0 * nq * nkv * h * 128
+        if not durs:
+            return None
+        avg = sum(durs) / len(durs)
+        return {"launches": len(durs), "avg_s": avg, "flops_per_launch": flops, "tflops": flops / avg / 1e12}
+
+
+def cpu_baseline(args, n_tokens, frames, steps):
+    """The CPU oracle ("port" of the reference's PyTorch path, pinned bit-exact to it by tests/golden) timed on the
+    host cores on a bounded sample, extrapolated to the clip: one full-width DiT block at Ns tokens (GEMM part scaled
+    by N/Ns, SDPA part by (N/Ns)^2, x30 blocks x2 CFG branches x steps) + VAE38 decode of a (1,48,2,4,4) latent scaled by
+    pixel-frames."""
+    from fairygen_amd import synthetic
+    from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
+    from oracle import wan_dit, wan_vae
+    cfg = dict(TI2V_5B_DIT_KWARGS, num_layers=1)
+    shapes = {k: v for k, v in synthetic.dit_shapes(cfg).items() if k.startswith("blocks.0.")}
+    sd = synthetic.random_state_dict(shapes, seed=5)
+    ns = args.cpu_tokens
+    f, h, w = 1, 64, ns // 64
+    x, ctx = seeded((1, ns, 3072), 6), seeded((1, 512, 3072), 7)
+    t_mod = seeded((1, 6, 3072), 8)
+    table = wan_dit.rope_table_3d(128, f, h, w)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        wan_dit.dit_block(sd, "blocks.0", x, ctx, t_mod, table, 24, 1e-6)
+        t_block = time.perf_counter() - t0
+        q = seeded((1, ns, 3072), 9)
+        t0 = time.perf_counter()
+        wan_dit.attention(q, q, q, 24)
+        t_attn = time.perf_counter() - t0
+        r = n_tokens / ns
+        t_forward = 30 * ((t_block - t_attn) * r + t_attn * r * r)
+        vsd = synthetic.random_state_dict(synthetic.vae_shapes(), seed=1234, only_prefix="model.dec") \
+            | synthetic.random_state_dict({"model.conv2.weight": (48, 48, 1, 1, 1), "model.conv2.bias": (48,)}, seed=2)
+        z = seeded((1, 48, 2, 4, 4), 10)
+        t0 = time.perf_counter()
+        wan_vae.decode(vsd, z)
+        t_vae_s = time.perf_counter() - t0
+    lat_t = (frames - 1) // 4 + 1
+    vae_scale = (args.height // 16) * (args.width // 16) * (4 * lat_t - 3) / (4 * 4 * 5)
+    t_clip = t_forward * 2 * steps + t_vae_s * vae_scale * (2.21 if not args.untiled and args.height > 480 else 1.0)
+    return {"value": frames / t_clip, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of 30 full-width DiT blocks at {ns} tokens ({t_block:.1f}s, SDPA {t_attn:.1f}s) scaled to N={n_tokens} "
+                      f"(GEMM~N, SDPA~N^2) x30 x2 x{steps} steps + full-width VAE38 decode of a (1,48,2,4,4) latent ({t_vae_s:.1f}s) "
+                      f"scaled by pixel-frames; extrapolated sec/clip = {t_clip:.0f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=704)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--frames", type=int, default=121)
+    ap.add_argument("--untiled", action="store_true", help="single_decode instead of the reference's tiled=True decode")
+    ap.add_argument("--no-lora", action="store_true")
+    ap.add_argument("--layers", type=int, default=0, help="debug: fewer DiT layers (reported in config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=4096)
+    ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from fairygen_amd import hip
+    hip.load()
+    pipe, cfg = build_pipeline(args, device)
+    if world > 1:
+        pipe.enable_sequence_parallel()
+    H, W, F_ = args.height, args.width, args.frames
+    lat_shape = (1, 48, (F_ - 1) // 4 + 1, H // 16, W // 16)
+    n_tokens = lat_shape[2] * (lat_shape[3] // 2) * (lat_shape[4] // 2)
+    noise = seeded(lat_shape, 1).to(device)
+    ctx_p = seeded((1, 512, 4096), 2); ctx_p[:, 64:] = 0
+    ctx_n = seeded((1, 512, 4096), 3); ctx_n[:, 128:] = 0
+    ctx_p, ctx_n = ctx_p.to(device), ctx_n.to(device)
+    z0 = seeded((1, 48, 1, lat_shape[3], lat_shape[4]), 4).to(device)
+
+    def run_clip(steps, decode):
+        pipe.scheduler.set_timesteps(steps, denoising_strength=1.0, shift=5.0)
+        latents = noise.clone()
+        latents[:, :, 0:1] = z0
+        shared = {"latents": latents, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0}
+        latents = pipe.denoise(shared, {"context": ctx_p}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x)
+        if not decode:
+            return latents, None
+        video = pipe.decode_latents(latents, tiled=not args.untiled)
+        return latents, video
+
+    with torch.no_grad():
+        # warmup: W denoise steps at full shape + a small decode (packs the VAE weights, warms the allocator)
+        if args.warmup > 0:
+            run_clip(args.warmup, decode=False)
+        if not args.skip_vae:
+            pipe.vae.decode(noise[:, :, :2, :8, :8].contiguous(), device=device, tiled=False)
+        torch.cuda.synchronize()
+        timer = KernelTimer()
+        timer.install()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        latents, video = run_clip(args.steps, decode=not args.skip_vae)
+        torch.cuda.synchronize()
+        t_denoise_and_decode = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_clip = time.perf_counter() - t0
+        timer.uninstall()
+    if world > 1:
+        tt = torch.tensor([t_clip], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_clip = tt.item()
+
+    if rank == 0:
+        st = timer.self_attention_stats()
+        roofline = None
+        if st:
+            roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel (fg_attn_fwd_bf16, self-attention launches)",
+                        "achieved": round(st["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(st["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches": st["launches"], "avg_launch_ms": round(st["avg_s"] * 1e3, 3),
+                        "flops_per_launch": st["flops_per_launch"]}
+        line = {
+            "metric": "decoded frames/sec (sec/clip in config), Wan2.2-TI2V-5B 704x1280x121 @ 50 steps",
+            "value": round(F_ / t_clip, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_clip / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Wan2.2-TI2V-5B {H}x{W}x{F_} TI2V clip: {args.steps} denoise steps (CFG 5.0, 2 forwards/step) + "
+                                   f"{'untiled' if args.untiled else 'tiled (30,52)/(15,26)'} VAE38 decode",
+                       "sec_per_clip": round(t_clip, 2), "tokens": n_tokens, "num_inference_steps": args.steps,
+                       "lora": "rank-32 merged, fused at load" if not args.no_lora else "none",
+                       "parallelism": f"sp{world}" if world > 1 else "single",
+                       "weights": "random-init bf16, reference key/shape set"},
+            "roofline": roofline,
+        }
+        if args.layers:
+            line["config"]["DEBUG_num_layers"] = args.layers
+        if args.skip_vae:
+            line["config"]["DEBUG_skip_vae"] = True
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, n_tokens, F_, args.steps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,11 +35,18 @@ def ulp_diff(a, b):
     return (a - b).abs().max().item()
 
 
-def assert_close_bf16(got, want, rel_ulps=1.0, what=""):
+def assert_close_bf16(got, want, rel_ulps=1.0, what="", mag=None, max_mismatch=2e-3):
+    """got == want up to `rel_ulps` bf16 ulps of `mag` (default |want|; pass the magnitude of the largest
+    rounded intermediate when the result is a cancelling sum: a 1-ulp flip of an intermediate, caused by a
+    different fp32 reduction order inside the row statistic, is 1 ulp of THAT magnitude), and bit-identical
+    in all but a `max_mismatch` fraction of the elements."""
     got, want = got.float().cpu(), want.float().cpu()
-    tol = rel_ulps * (want.abs().clamp_min(1e-3) * 2.0 ** -7)       # 1 bf16 ulp ~ 2^-7 relative (upper bound)
+    mag = want.abs() if mag is None else torch.maximum(want.abs(), mag.float().cpu().abs().expand_as(want))
+    tol = rel_ulps * (mag.clamp_min(1e-3) * 2.0 ** -7)       # 1 bf16 ulp <= 2^-7 relative
     bad = ((got - want).abs() > tol)
     assert not bad.any(), f"{what}: {bad.sum().item()} / {bad.numel()} beyond {rel_ulps} ulp; max abs {(got - want).abs().max().item()}"
+    frac = (got != want).float().mean().item()
+    assert frac <= max_mismatch, f"{what}: {frac:.2e} of the elements differ from the oracle (allowed {max_mismatch:.0e})"
 
 
 # ------------------------------------------------------------------------------------------ DiT elementwise
@@ -54,7 +61,7 @@ def test_ln_modulate(hip, rows, C, mod_rows):
         (torch.arange(rows) >= first).long() if mod_rows == 2 else torch.arange(rows))
     shift, scale = table[idx, 0].unsqueeze(0), table[idx, 1].unsqueeze(0)
     want = wan_dit.layer_norm(x, 1e-6) * (1 + scale) + shift
-    assert_close_bf16(got, want, 1.0, "ln_modulate")
+    assert_close_bf16(got, want, 1.0, "ln_modulate", mag=shift)
 
 
 def test_ln_affine_and_gate_residual(hip):
@@ -62,7 +69,7 @@ def test_ln_affine_and_gate_residual(hip):
     x, y = seeded((1, rows, C), 3), seeded((1, rows, C), 4)
     w, b = 1 + 0.1 * seeded((C,), 5), 0.1 * seeded((C,), 6)
     w, b = w.to(torch.bfloat16), b.to(torch.bfloat16)
-    assert_close_bf16(hip.ln_affine(dev(x), dev(w), dev(b), 1e-6), wan_dit.layer_norm(x, 1e-6, w, b), 1.0, "ln_affine")
+    assert_close_bf16(hip.ln_affine(dev(x), dev(w), dev(b), 1e-6), wan_dit.layer_norm(x, 1e-6, w, b), 1.0, "ln_affine", mag=b)
     table = seeded((2, 6, C), 7)
     mod = hip.ModTable(dev(table), 30)
     idx = (torch.arange(rows) >= 30).long()
@@ -80,14 +87,15 @@ def test_fused_residual_norms(hip):
     x1 = x + table[idx, 5].unsqueeze(0) * y
     xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, 5, 0, 1, 1e-6, norm_mod=mod2)
     assert torch.equal(xo.cpu(), x1)
-    assert_close_bf16(no, wan_dit.layer_norm(x1, 1e-6) * (1 + table2[idx, 1].unsqueeze(0)) + table2[idx, 0].unsqueeze(0), 1.0, "res+modulate")
+    assert_close_bf16(no, wan_dit.layer_norm(x1, 1e-6) * (1 + table2[idx, 1].unsqueeze(0)) + table2[idx, 0].unsqueeze(0), 1.0, "res+modulate",
+                      mag=table2[idx, 0].unsqueeze(0))
     xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, None, 3, 4, 1e-6)
     assert torch.equal(xo.cpu(), x + y)
     w, b = (1 + 0.1 * seeded((C,), 5)).to(torch.bfloat16), (0.1 * seeded((C,), 6)).to(torch.bfloat16)
     xo, no = hip.residual_ln_affine(dev(x), dev(y), dev(w), dev(b), 1e-6, mod, 2)
     x2 = x + table[idx, 2].unsqueeze(0) * y
     assert torch.equal(xo.cpu(), x2)
-    assert_close_bf16(no, wan_dit.layer_norm(x2, 1e-6, w, b), 1.0, "res+affine")
+    assert_close_bf16(no, wan_dit.layer_norm(x2, 1e-6, w, b), 1.0, "res+affine", mag=b)
 
 
 @pytest.mark.parametrize("heads,C,grid", [(24, 3072, (2, 3, 5)), (2, 256, (3, 4, 4))])
@@ -108,8 +116,8 @@ def test_rmsnorm_rope(hip, heads, C, grid):
 
 def test_activations_and_cfg_euler(hip):
     x = seeded((3, 1000, 8), 14, scale=3.0)
-    assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu")
-    assert_close_bf16(hip.activation(dev(x).clone(), "gelu_tanh"), F.gelu(x, approximate="tanh"), 1.0, "gelu")
+    assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu", max_mismatch=0.05)          # __expf vs libm: rare 1-ulp flips
+    assert_close_bf16(hip.activation(dev(x).clone(), "gelu_tanh"), F.gelu(x, approximate="tanh"), 1.0, "gelu", max_mismatch=0.05)
     lat, p, n_ = seeded((1, 48, 3, 8, 8), 15), seeded((1, 48, 3, 8, 8), 16), seeded((1, 48, 3, 8, 8), 17)
     sig, _ = opipe.wan_sigmas(4)
     for i in range(4):
