@@ -187,9 +187,12 @@ def main():
         latents = pipe.denoise(shared, {"context": ctx_p}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x)
         if not decode:
             return latents, None
+        torch.cuda.synchronize()
+        phase["denoise_s"] = time.perf_counter() - phase["t0"]
         video = pipe.decode_latents(latents, tiled=not args.untiled)
         return latents, video
 
+    phase = {}
     with torch.no_grad():
         # warmup: W denoise steps at full shape + a small decode (packs the VAE weights, warms the allocator)
         if args.warmup > 0:
@@ -202,7 +205,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0 = phase["t0"] = time.perf_counter()
         latents, video = run_clip(args.steps, decode=not args.skip_vae)
         torch.cuda.synchronize()
         t_denoise_and_decode = time.perf_counter() - t0
@@ -232,7 +235,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Wan2.2-TI2V-5B {H}x{W}x{F_} TI2V clip: {args.steps} denoise steps (CFG 5.0, 2 forwards/step) + "
                                    f"{'untiled' if args.untiled else 'tiled (30,52)/(15,26)'} VAE38 decode",
-                       "sec_per_clip": round(t_clip, 2), "tokens": n_tokens, "num_inference_steps": args.steps,
+                       "sec_per_clip": round(t_clip, 2), "denoise_s": round(phase.get("denoise_s", t_clip), 2),
+                       "vae_decode_s": round(t_clip - phase.get("denoise_s", t_clip), 2), "tokens": n_tokens, "num_inference_steps": args.steps,
                        "lora": "rank-32 merged, fused at load" if not args.no_lora else "none",
                        "parallelism": f"sp{world}" if world > 1 else "single",
                        "weights": "random-init bf16, reference key/shape set"},

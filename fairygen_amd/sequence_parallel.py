@@ -62,3 +62,9 @@ class TokenShard:
         if self.world_size == 1:
             return x
         return self._gather_rows(x[0], self.chunk(n))[:n].unsqueeze(0).contiguous()
+
+    def broadcast(self, tensor, src):
+        """In-place broadcast from group rank `src` (VAE tiles decoded round-robin over ranks)."""
+        if self.world_size > 1:
+            dist.broadcast(tensor, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        return tensor

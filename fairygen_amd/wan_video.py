@@ -295,11 +295,16 @@ class WanVideoPipeline(torch.nn.Module):
             inputs_shared, _, _ = self.unit_runner(unit, self, inputs_shared, inputs_posi, inputs_nega)
 
         # Decode (reference :322-325)
-        video = self.vae.decode(inputs_shared["latents"], device=self.device, tiled=tiled, tile_size=tile_size,
-                                tile_stride=tile_stride)
+        video = self.decode_latents(inputs_shared["latents"], tiled=tiled, tile_size=tile_size, tile_stride=tile_stride)
         if output_type == "quantized":
             video = self.vae_output_to_video(video)
         return video
+
+    def decode_latents(self, latents, tiled=True, tile_size=(30, 52), tile_stride=(15, 26)):
+        """vae.decode on the device (reference :322-323); tiles go round-robin over the sequence-parallel ranks."""
+        shard = self.sequence_shard if (self.sequence_shard is not None and self.sequence_shard.world_size > 1) else None
+        return self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
+                               shard=shard)
 
     def denoise(self, inputs_shared, inputs_posi, inputs_nega, cfg_scale, progress_bar_cmd=tqdm):
         """The hot loop: per step forward(+), forward(-), then CFG combine + Euler step fused in one HIP kernel,

@@ -327,32 +327,46 @@ class WanVideoVAE38(nn.Module):
                 tasks.append((h, h + size_h, w, w + size_w))
         return tasks
 
-    def tiled_decode(self, hidden_states, device, tile_size, tile_stride):
-        """Same tiles, masks and bf16 accumulation as the reference (:1103-1152), but the canvas lives in HBM
-        (654 MB at 704x1280x121) instead of bouncing every tile through host memory."""
+    def tiled_decode(self, hidden_states, device, tile_size, tile_stride, shard=None):
+        """Same tiles, masks and bf16 accumulation ORDER as the reference (:1103-1152), but the canvas lives in HBM
+        (654 MB at 704x1280x121) instead of bouncing every tile through host memory.  With a multi-rank `shard`
+        (sequence_parallel.TokenShard) tile i is decoded by rank i % world and broadcast; every rank then blends
+        all tiles in the reference's order, so the result is identical to the single-GPU one."""
         _, _, T, H, W = hidden_states.shape
         up = self.upsampling_factor
         out_T = T * 4 - 3
         z = hidden_states.to(device)
         weight = torch.zeros((1, 1, out_T, H * up, W * up), dtype=z.dtype, device=device)
         values = torch.zeros((1, 3, out_T, H * up, W * up), dtype=z.dtype, device=device)
-        for h, h_, w, w_ in self.tile_tasks(H, W, tile_size, tile_stride):
-            tile = self.model.decode(z[:, :, :, h:h_, w:w_].contiguous(), self.scale)
+        tasks = self.tile_tasks(H, W, tile_size, tile_stride)
+        world, rank = (shard.world_size, shard.rank) if shard is not None else (1, 0)
+        tiles = {}
+        for i, (h, h_, w, w_) in enumerate(tasks):
+            if i % world == rank:
+                tiles[i] = self.model.decode(z[:, :, :, h:h_, w:w_].contiguous(), self.scale)
+        for i, (h, h_, w, w_) in enumerate(tasks):
+            if world > 1:
+                th, tw = (min(h_, H) - h) * up, (min(w_, W) - w) * up
+                tile = tiles.pop(i) if i in tiles else torch.empty((1, 3, out_T, th, tw), dtype=z.dtype, device=device)
+                shard.broadcast(tile, src=i % world)
+            else:
+                tile = tiles.pop(i)
             hip.vae_tile_accumulate(tile[0], values[0], weight[0, 0], h * up, w * up,
                                     (tile_size[0] - tile_stride[0]) * up, (tile_size[1] - tile_stride[1]) * up,
                                     (h == 0, h_ >= H, w == 0, w_ >= W))
+            del tile
         hip.vae_tile_finalize(values[0], weight[0, 0])
         return values
 
     def single_decode(self, hidden_state, device):
         return self.model.decode(hidden_state.to(device), self.scale, clamp=True)
 
-    def decode(self, hidden_states, device, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
+    def decode(self, hidden_states, device, tiled=False, tile_size=(34, 34), tile_stride=(18, 16), shard=None):
         """(B,48,T,h,w) -> (B,3,F,H,W) in [-1,1], kept on `device` (:1235-1247)."""
         videos = []
         for hidden_state in hidden_states:
             hidden_state = hidden_state.unsqueeze(0)
-            video = self.tiled_decode(hidden_state, device, tile_size, tile_stride) if tiled \
+            video = self.tiled_decode(hidden_state, device, tile_size, tile_stride, shard) if tiled \
                 else self.single_decode(hidden_state, device)
             videos.append(video.squeeze(0))
         return torch.stack(videos)
