@@ -1,0 +1,159 @@
+"""CPU-side tests: C-ABI surface, model identification, scheduler / LoRA / pipeline plumbing mirrors, and the
+loud-failure contract (no CPU fallback).  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO, seeded
+from fairygen_amd import ModelConfig, WanVideoPipeline, hip, loader, synthetic
+from fairygen_amd.flow_match import FlowMatchScheduler
+from fairygen_amd.lora import GeneralLoRALoader, merge_lora_weights
+from fairygen_amd.wan_video_dit import WanModel
+from fairygen_amd.wan_video_vae import WanVideoVAE38
+from oracle import wan_vae
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "fairygen_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", header)))
+    assert declared == hip.EXPORTED_SYMBOLS
+    lib = ctypes.CDLL(hip.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.load().fg_version() == hip.ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    q = seeded((1, 8, 256), 1)
+    with pytest.raises(hip.HipLibraryError, match="no CPU fallback"):
+        hip.attention(q, q, q, 2)
+    with pytest.raises(hip.HipLibraryError):
+        hip.activation(q, "silu")
+    with pytest.raises(hip.HipLibraryError):
+        hip.vae_rmsnorm_silu(q, q[0, 0], True)
+
+
+def test_argument_validation_through_the_c_abi():
+    lib = hip.load()
+    rc = lib.fg_attn_fwd_bf16(None, 0, None, 0, None, 0, None, 1, 1, 1, 1, 128, 1.0, None)
+    assert rc == -1 and b"null pointer" in lib.fg_last_error()
+    rc = lib.fg_conv3d_cl_bf16(ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16), None, ctypes.c_void_p(16),
+                               1, 4, 4, 8, 8, 2, 3, 0, 0, None)
+    assert rc == -1 and b"kt and ks" in lib.fg_last_error()
+    assert lib.fg_conv_packed_bytes(12, 256, 3, 3, 3) == 27 * 128 * 256 * 2
+    assert lib.fg_conv_packed_bytes(1024, 48, 3, 3, 3) == 27 * 1024 * 64 * 2
+
+
+def test_key_hashes_match_the_reference_table():
+    # configs/model_configs.py:289-302 of the reference
+    dit = {k: list(v) for k, v in synthetic.dit_shapes().items()}
+    vae = {k: list(v) for k, v in synthetic.vae_shapes(with_prefix=False).items()}
+    assert len(dit) == 825
+    assert loader.hash_keys_dict(dit) == "1f5ab7703c6fc803fdded85ff040c316"
+    assert loader.hash_keys_dict(vae) == "e1de6c02cdac79f8b739f4d3698cd216"
+
+
+def test_model_pool_loads_by_hash_and_rejects_unknown(tmp_path):
+    cfg = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    path = synthetic.save_checkpoint(sd, str(tmp_path / "dit.safetensors"))
+    pool = loader.ModelPool()
+    with pytest.raises(ValueError, match="Cannot detect the model type"):
+        pool.auto_load_model(path)
+    loader.register_model_config({"model_hash": loader.hash_model_file(path), "model_name": "wan_video_dit",
+                                  "model_class": "fairygen_amd.wan_video_dit.WanModel", "extra_kwargs": cfg})
+    pool.auto_load_model(path)
+    m = pool.fetch_model("wan_video_dit", index=2)
+    assert isinstance(m, WanModel) and m.blocks[1].ffn[2].weight.dtype == torch.bfloat16
+    assert torch.equal(m.state_dict()["blocks.0.modulation"], sd["blocks.0.modulation"])
+    assert m.freqs[0].dtype == torch.complex128 and not m.freqs[0].is_meta
+    assert pool.fetch_model("wan_video_vae") is None
+    with pytest.raises(RuntimeError, match="offline"):
+        ModelConfig(model_id="Wan-AI/Wan2.2-TI2V-5B", origin_file_pattern="Wan2.2_VAE.pth").download_if_necessary()
+    with pytest.raises(ValueError):
+        ModelConfig().download_if_necessary()
+
+
+def test_scheduler_mirror(golden):
+    g = golden("scheduler.safetensors")
+    for n in (4, 30, 50):
+        s = FlowMatchScheduler("Wan")
+        s.set_timesteps(n, denoising_strength=1.0, shift=5.0)
+        assert torch.equal(s.sigmas, g[f"sigmas_{n}"]) and torch.equal(s.timesteps, g[f"timesteps_{n}"])
+    s = FlowMatchScheduler("Wan")
+    s.set_timesteps(4, shift=5.0)
+    sig, nxt = s.step_scalars(s.timesteps[3])
+    assert float(nxt) == 0.0 and float(sig) == float(s.sigmas[3])
+    sig, nxt = s.step_scalars(s.timesteps[1].to(torch.bfloat16))       # bf16-rounded timestep still finds its slot
+    assert float(sig) == float(s.sigmas[1]) and float(nxt) == float(s.sigmas[2])
+    with pytest.raises(NotImplementedError):
+        FlowMatchScheduler("FLUX.1")
+
+
+def test_lora_loader_mirror(golden):
+    g = golden("lora.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    shapes = synthetic.dit_shapes(cfg)
+    m = WanModel(**cfg).to(torch.bfloat16)
+    m.load_state_dict(synthetic.random_state_dict(shapes, seed=1234))
+    lora = synthetic.random_lora(shapes, rank=4, seed=4321)
+    ld = GeneralLoRALoader(device="cpu", torch_dtype=torch.bfloat16)
+    conv = ld.convert_state_dict(lora)
+    assert ld.convert_state_dict(conv).keys() == conv.keys()                      # idempotent
+    up_down = {k.replace("lora_B.default", "lora_up.x").replace("lora_A.default", "lora_down.x"): v for k, v in lora.items()}
+    assert set(ld.convert_state_dict({"diffusion_model." + k: v for k, v in up_down.items()})) == set(conv)
+    m.blocks[0].fused_weights()
+    assert ld.fuse_lora_to_base_model(m, conv, alpha=0.5) == 20
+    assert m.blocks[0]._fused is None                                             # fused QKV cache invalidated
+    fused = m.state_dict()
+    for k in ("blocks.0.self_attn.q.weight", "blocks.1.cross_attn.v.weight", "blocks.1.ffn.2.weight", "blocks.0.ffn.0.weight",
+              "blocks.0.self_attn.q.bias"):
+        assert torch.equal(fused[k], g[k]), k
+    stage2 = {k.replace(".lora_B.default.weight", ".lora_B2.weight"): seeded(v.shape, 77 + i, scale=0.02)
+              for i, (k, v) in enumerate(sorted(lora.items())) if ".lora_B." in k}
+    merged = merge_lora_weights(lora, stage2)
+    assert torch.equal(merged["blocks.0.self_attn.q.lora_B.default.weight"], g["merged.blocks.0.self_attn.q.lora_B"])
+
+
+def _cpu_pipe():
+    pipe = WanVideoPipeline(device="cpu", torch_dtype=torch.bfloat16)
+    pipe.dit = WanModel(**synthetic.TINY_DIT_KWARGS).to(torch.bfloat16)
+    pipe.vae = WanVideoVAE38(dim=32, dec_dim=32).to(torch.bfloat16)
+    pipe.height_division_factor = pipe.width_division_factor = pipe.vae.upsampling_factor * 2
+    return pipe
+
+
+def test_pipeline_units_and_call_surface(golden):
+    pipe = _cpu_pipe()
+    assert pipe.check_resize_height_width(470, 830, 80) == (480, 832, 81)
+    assert torch.equal(pipe.generate_noise((1, 48, 2, 4, 4), seed=1), golden("pixels.safetensors")["noise_seed1"])
+    shared = {"height": 64, "width": 64, "num_frames": 9, "seed": 1, "rand_device": "cpu", "cfg_scale": 5.0, "input_video": None,
+              "input_image": None, "first_frame_latents": seeded((1, 48, 1, 4, 4), 4), "tiled": True, "tile_size": (3, 3),
+              "tile_stride": (2, 2)}
+    posi, nega = {"prompt": seeded((1, 16, 128), 2)}, {"negative_prompt": seeded((1, 16, 128), 3)}
+    for unit in pipe.units:
+        shared, posi, nega = pipe.unit_runner(unit, pipe, shared, posi, nega)
+    assert shared["latents"].shape == (1, 48, 3, 4, 4) and shared["fuse_vae_embedding_in_latents"] is True
+    assert torch.equal(shared["latents"][:, :, 0:1], shared["first_frame_latents"])
+    assert torch.equal(posi["context"], seeded((1, 16, 128), 2)) and torch.equal(nega["context"], seeded((1, 16, 128), 3))
+    # model_fn / vae.decode are the reference's plug points: swap them for recorders, the loop math is GPU-only
+    with pytest.raises(RuntimeError, match="text encoder"):
+        pipe(prompt="a pig walks", seed=1, height=64, width=64, num_frames=9)
+    with pytest.raises(NotImplementedError):
+        pipe(prompt=posi["prompt"], vace_video=[1], height=64, width=64, num_frames=9)
+    with pytest.raises(TypeError):
+        pipe(prompt=posi["prompt"], bogus=1)
+    with pytest.raises(hip.HipLibraryError):        # the hot loop refuses to run on CPU tensors
+        pipe(prompt=posi["prompt"], negative_prompt=nega["negative_prompt"], first_frame_latents=shared["first_frame_latents"],
+             seed=1, height=64, width=64, num_frames=9, num_inference_steps=1, progress_bar_cmd=lambda x: x)
+
+
+def test_tile_grid_matches_oracle():
+    for hw in ((44, 80), (30, 52), (6, 8), (31, 53)):
+        for size, stride in (((30, 52), (15, 26)), ((34, 34), (18, 16)), ((3, 4), (2, 2))):
+            assert WanVideoVAE38.tile_tasks(*hw, size, stride) == wan_vae.tile_tasks(*hw, size, stride)
+    assert len(WanVideoVAE38.tile_tasks(44, 80, (30, 52), (15, 26))) == 6
+    assert len(WanVideoVAE38.tile_tasks(30, 52, (30, 52), (15, 26))) == 1
