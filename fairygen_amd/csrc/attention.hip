@@ -6,15 +6,20 @@
 //
 // Structure (one workgroup = 8 waves = 256 query rows of one head, 2 waves per SIMD):
 //   * each wave owns 32 query rows; Q^T fragments live in registers for the whole kernel (32 VGPRs);
-//   * K/V tiles of 64 keys are staged global -> registers -> LDS, double buffered, loads for tile t+1
-//     issued before the math of tile t (issue-early / write-late), one barrier per tile;
-//   * S^T = K * Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): every lane ends up with 32 scores
-//     of ONE query row, so the row max / row sum are lane-local plus a single lane<->lane+32 exchange;
-//   * the S^T accumulators, converted pairwise to bf16, are directly the B operand of
-//     O^T += V^T * P^T (no LDS round trip for P); V^T fragments come from the row-major V tile through
-//     ds_read_b64_tr_b16 (hardware transpose);
+//   * K/V tiles of 64 keys are staged global -> registers -> LDS (issue-early / write-late), K two tiles ahead
+//     and V one tile ahead, 2 LDS buffers each, ONE barrier per tile;
+//   * software pipeline inside a wave: S^T(t+1) = K(t+1) Q^T is issued on the matrix pipe WHILE the VALU runs
+//     the online softmax of tile t (two score tiles live, statically named so nothing goes to scratch), then
+//     O^T += V(t)^T P(t)^T; the loop body is branch-free so MFMA / VALU / LDS instructions interleave;
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): every lane holds 32 scores of ONE query row,
+//     so row max / row sum are lane-local plus one lane<->lane+32 exchange, and the S^T accumulators, converted
+//     pairwise to bf16, are directly the B operand of O^T += V^T P^T (no LDS round trip for P);
+//     V^T fragments come from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
+//   * the O^T accumulators are rescaled only when some row's running max grew by more than 2^kDeferLog2
+//     (deferred rescale: P stays bounded by 2^kDeferLog2, exact up to bf16 rounding of P);
 //   * K tile: 256-B rows, 16-B chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128;
 //     V tile: 8-row x 32-column sub-tiles of 512 B with a chunk XOR -> conflict-free transposed reads;
+//     all LDS addresses are loop-invariant per-lane bases + immediates;
 //   * workgroup -> (head, q-block) map is XCD-aware: the 8 XCDs each walk a contiguous range of heads, so
 //     the 32 CUs sharing an L2 stream the SAME head's K/V at the same time.
 #include "common.h"
@@ -27,6 +32,7 @@ constexpr int kWaves = 8;
 constexpr int kBM = 32 * kWaves;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kTileBytes = kBN * kD * 2;  // 16 KiB
+constexpr float kDeferLog2 = 6.0f;        // rescale O only if a row max grows by > 2^6 (P <= 64)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -85,24 +91,45 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(
     // ---- tile staging: thread t moves rows (t>>4) and (t>>4)+32, 16-byte chunk (t&15), of K and V.
     const int st_row = tid >> 4, st_chunk = tid & 15;
     const int nt = (int)((Nkv + kBN - 1) / kBN);
+    const int st_k0 = k_lds_off(st_row, st_chunk), st_k1 = k_lds_off(st_row + 32, st_chunk);
+    const int st_v0 = v_lds_off(st_row, st_chunk), st_v1 = v_lds_off(st_row + 32, st_chunk);
     u32x4 kreg[2], vreg[2];
-    auto stage_load = [&](int t) {
+    auto load_k = [&](int t) {      // tile index is clamped: past-the-end tiles reload the last one (never used)
+        if (t >= nt) t = nt - 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int64_t row = (int64_t)t * kBN + st_row + 32 * i;
             if (row >= Nkv) row = Nkv - 1;
             kreg[i] = *reinterpret_cast<const u32x4*>(kp + row * ldk + st_chunk * 8);
+        }
+    };
+    auto load_v = [&](int t) {
+        if (t >= nt) t = nt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int64_t row = (int64_t)t * kBN + st_row + 32 * i;
+            if (row >= Nkv) row = Nkv - 1;
             vreg[i] = *reinterpret_cast<const u32x4*>(vp + row * ldv + st_chunk * 8);
         }
     };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = st_row + 32 * i;
-            *reinterpret_cast<u32x4*>(k_lds + buf * kTileBytes + k_lds_off(row, st_chunk)) = kreg[i];
-            *reinterpret_cast<u32x4*>(v_lds + buf * kTileBytes + v_lds_off(row, st_chunk)) = vreg[i];
-        }
+    auto write_k = [&](int buf) {
+        *reinterpret_cast<u32x4*>(k_lds + buf * kTileBytes + st_k0) = kreg[0];
+        *reinterpret_cast<u32x4*>(k_lds + buf * kTileBytes + st_k1) = kreg[1];
     };
+    auto write_v = [&](int buf) {
+        *reinterpret_cast<u32x4*>(v_lds + buf * kTileBytes + st_v0) = vreg[0];
+        *reinterpret_cast<u32x4*>(v_lds + buf * kTileBytes + st_v1) = vreg[1];
+    };
+
+    // ---- loop-invariant per-lane LDS read addresses
+    int k_rd[8];      // K fragment of k-step ks, sub-tile 0 (sub-tile 1: + 32 rows = + 8192 B)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) k_rd[ks] = k_lds_off(r, 2 * ks + hh);
+    // transposed V reads: group g = lane>>4 (g>>1 == hh), i = lane&15, q_ = i>>2, p_ = i&3; block rows 16kk + 8u + 4hh + q_,
+    // chunk 4db + 2(g&1) + (p_>>1): offset = base_u + 4096*kk + 512*db  (u = 0/1: second read is 8 rows further)
+    const int tr_g1 = (lane >> 4) & 1, tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int v_rd0 = v_lds_off(4 * hh + tr_q, 2 * tr_g1 + (tr_p >> 1)) + 8 * (tr_p & 1);
+    const int v_rd1 = v_lds_off(8 + 4 * hh + tr_q, 2 * tr_g1 + (tr_p >> 1)) + 8 * (tr_p & 1);
 
     f32x16 o[4];
 #pragma unroll
@@ -111,81 +138,75 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(
         for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // per-lane pieces of the transposed-read address: group g = lane>>4, i = lane&15, q_ = i>>2, p_ = i&3
-    const int tr_g1 = (lane >> 4) & 1, tr_q = (lane & 15) >> 2, tr_p = lane & 3;
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        const bool has_next = t + 1 < nt;
-        if (has_next) stage_load(t + 1);
-
-        // ---- S^T = K Q^T : two 32-key sub-tiles, 8 k-steps of 16 over d
-        f32x16 s[2];
-        const char* kb = k_lds + cur * kTileBytes;
+    auto qk_tile = [&](f32x16 (&s)[2], int buf) {
+        const char* kb = k_lds + buf * kTileBytes;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) s[sub][j] = 0.f;
-            const int krow = sub * 32 + r;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + k_lds_off(krow, 2 * ks + hh));
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb + k_rd[ks] + sub * 8192);
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[sub], 0, 0, 0);
             }
         }
-        // s[sub][reg] = score(key = 64t + 32sub + (reg&3) + 8(reg>>2) + 4hh, query r)
-        if ((int64_t)(t + 1) * kBN > Nkv) {  // ragged last tile (wave-uniform branch)
-            const int64_t kbase = (int64_t)t * kBN + 4 * hh;
+    };
+    // s[sub][reg] = score(key = 64t + 32sub + (reg&3) + 8(reg>>2) + 4hh, query r)
+    auto mask_tile = [&](f32x16 (&s)[2], int t) {
+        const int64_t kbase = (int64_t)t * kBN + 4 * hh;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (kbase + 32 * sub + (j & 3) + 8 * (j >> 2) >= Nkv) s[sub][j] = -INFINITY;
-        }
+            for (int j = 0; j < 16; ++j)
+                if (kbase + 32 * sub + (j & 3) + 8 * (j >> 2) >= Nkv) s[sub][j] = -INFINITY;
+    };
 
-        // ---- online softmax in the log2 domain
-        float mt = s[0][0];
+    // One pipeline step for tile t: sc = scores(t) (ready), sn <- scores(t+1) while softmax(sc) runs, then PV(t).
+    auto step = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t) {
+        const int cur = t & 1;
+        load_k(t + 2);
+        load_v(t + 1);
+
+        // ---- S^T(t+1) on the matrix pipe ...
+        qk_tile(sn, cur ^ 1);
+        // ---- ... under the online softmax of tile t (log2 domain) on the VALU
+        float mt = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
-        for (int j = 1; j < 16; ++j) mt = fmaxf(mt, s[0][j]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) mt = fmaxf(mt, s[1][j]);
+        for (int j = 1; j < 16; ++j) mt = fmaxf(mt, fmaxf(sc[0][j], sc[1][j]));
         mt = pair_max(mt);
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = fast_exp2((m_run - m_new) * scale_log2e);
-        const float mb = m_new * scale_log2e;
-        m_run = m_new;
+        // deferred rescale: keep the stale max while no row of the wave outgrew it by more than 2^kDeferLog2
+        const bool grow = (mt - m_run) * scale_log2e > kDeferLog2;      // also true on the first tile (m_run = -inf)
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = fast_exp2((m_run - m_new) * scale_log2e);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+        }
+        const float mb = m_run * scale_log2e;
         float psum = 0.f;
         bf16x8 pf[4];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float p = fast_exp2(s[sub][j] * scale_log2e - mb);
+                const float p = fast_exp2(sc[sub][j] * scale_log2e - mb);
                 psum += p;
                 pf[sub * 2 + (j >> 3)][j & 7] = (bf16)p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+        l_run += psum;
 
-        // ---- O^T += V^T P^T : 4 d-blocks x 4 k-steps of 16 keys
+        // ---- O^T += V(t)^T P^T : 4 d-blocks x 4 k-steps of 16 keys
         const char* vb = v_lds + cur * kTileBytes;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const int chunk = 4 * db + 2 * tr_g1 + (tr_p >> 1);
-                const int row0 = 16 * kk + 4 * hh + tr_q;
-                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4*)(vb + v_lds_off(row0, chunk) + 8 * (tr_p & 1)));
-                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4*)(vb + v_lds_off(row0 + 8, chunk) + 8 * (tr_p & 1)));
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + v_rd0 + 4096 * kk + 512 * db));
+                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + v_rd1 + 4096 * kk + 512 * db));
                 union { s16x4 h2[2]; bf16x8 f; } a;
                 a.h2[0] = t0;
                 a.h2[1] = t1;
@@ -193,9 +214,32 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(
             }
         }
 
-        if (has_next) stage_write(cur ^ 1);
+        // K(t+2) replaces K(t) (last read in step t-1), V(t+1) replaces V(t-1) (last read in step t-1)
+        write_k(cur);
+        write_v(cur ^ 1);
+        if ((int64_t)(t + 2) * kBN > Nkv && t + 1 < nt) mask_tile(sn, t + 1);      // ragged last tile (wave-uniform)
         __syncthreads();
+    };
+
+    // ---- prologue: K(0), V(0), K(1) resident; scores(0) computed
+    f32x16 sA[2], sB[2];
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    load_k(1);
+    write_k(1);
+    __syncthreads();
+    qk_tile(sA, 0);
+    if ((int64_t)kBN > Nkv) mask_tile(sA, 0);
+    __syncthreads();      // every wave is done with K(0) before step 0 overwrites it with K(2)
+
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        step(sA, sB, t);
+        step(sB, sA, t + 1);
     }
+    if (t < nt) step(sA, sB, t);
 
     // ---- epilogue: normalise and store O[query r][d = 32db + 8g + 4hh + 0..3]
     const float l_tot = pair_sum(l_run);
@@ -222,6 +266,7 @@ extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64
     FG_CHECK_ARG(q && k && v && out, "fg_attn_fwd_bf16: null pointer");
     FG_CHECK_ARG(D == kD, "fg_attn_fwd_bf16: only head_dim 128 is supported (got %d)", D);
     FG_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nkv > 0, "fg_attn_fwd_bf16: B, H, Nq, Nkv must be positive");
+    FG_CHECK_ARG(scale > 0.f, "fg_attn_fwd_bf16: scale must be positive");
     const int64_t hd = (int64_t)H * D;
     FG_CHECK_ARG(ldq >= hd && ldk >= hd && ldv >= hd && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0,
                  "fg_attn_fwd_bf16: leading dimensions must be >= H*D and multiples of 8");
