@@ -42,6 +42,12 @@ __device__ __forceinline__ int v_lds_off(int row, int chunk) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// One instruction; plain fmaxf() makes hipcc canonicalise every MFMA output first (3x the VALU work).
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // max / sum across the lane pair (l, l^32) that shares a query row.
 __device__ __forceinline__ float pair_max(float x) {
@@ -93,24 +99,24 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(
     const int nt = (int)((Nkv + kBN - 1) / kBN);
     const int st_k0 = k_lds_off(st_row, st_chunk), st_k1 = k_lds_off(st_row + 32, st_chunk);
     const int st_v0 = v_lds_off(st_row, st_chunk), st_v1 = v_lds_off(st_row + 32, st_chunk);
+    // Buffer descriptors (wave-uniform) bound the loads to the head's rows: rows >= Nkv (ragged last tile, prefetch
+    // past the end) come back as zeros from the hardware range check -- no clamps, 32-bit offsets.
+    const uint32_t k_bytes = (uint32_t)((Nkv - 1) * ldk * 2 + kD * 2), v_bytes = (uint32_t)((Nkv - 1) * ldv * 2 + kD * 2);
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(kp), 0, k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(vp), 0, v_bytes, 0x00020000);
+    const uint32_t k_tile_stride = (uint32_t)(kBN * ldk * 2), v_tile_stride = (uint32_t)(kBN * ldv * 2);
+    const uint32_t k_off0 = (uint32_t)(st_row * ldk * 2 + st_chunk * 16), k_off1 = k_off0 + (uint32_t)(32 * ldk * 2);
+    const uint32_t v_off0 = (uint32_t)(st_row * ldv * 2 + st_chunk * 16), v_off1 = v_off0 + (uint32_t)(32 * ldv * 2);
     u32x4 kreg[2], vreg[2];
-    auto load_k = [&](int t) {      // tile index is clamped: past-the-end tiles reload the last one (never used)
-        if (t >= nt) t = nt - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t row = (int64_t)t * kBN + st_row + 32 * i;
-            if (row >= Nkv) row = Nkv - 1;
-            kreg[i] = *reinterpret_cast<const u32x4*>(kp + row * ldk + st_chunk * 8);
-        }
+    auto load_k = [&](int t) {
+        const uint32_t base = (uint32_t)t * k_tile_stride;
+        kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_off0 + base, 0, 0);
+        kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_off1 + base, 0, 0);
     };
     auto load_v = [&](int t) {
-        if (t >= nt) t = nt - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t row = (int64_t)t * kBN + st_row + 32 * i;
-            if (row >= Nkv) row = Nkv - 1;
-            vreg[i] = *reinterpret_cast<const u32x4*>(vp + row * ldv + st_chunk * 8);
-        }
+        const uint32_t base = (uint32_t)t * v_tile_stride;
+        vreg[0] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_off0 + base, 0, 0);
+        vreg[1] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_off1 + base, 0, 0);
     };
     auto write_k = [&](int buf) {
         *reinterpret_cast<u32x4*>(k_lds + buf * kTileBytes + st_k0) = kreg[0];
@@ -170,10 +176,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(
         // ---- S^T(t+1) on the matrix pipe ...
         qk_tile(sn, cur ^ 1);
         // ---- ... under the online softmax of tile t (log2 domain) on the VALU
-        float mt = fmaxf(sc[0][0], sc[1][0]);
+        float mt = max3(sc[0][0], sc[1][0], sc[0][1]);
+        mt = max3(mt, sc[1][1], sc[0][2]);
 #pragma unroll
-        for (int j = 1; j < 16; ++j) mt = fmaxf(mt, fmaxf(sc[0][j], sc[1][j]));
-        mt = pair_max(mt);
+        for (int j = 2; j < 15; ++j) mt = max3(mt, sc[1][j], sc[0][j + 1]);
+        mt = pair_max(fmaxf(mt, sc[1][15]));
         // deferred rescale: keep the stale max while no row of the wave outgrew it by more than 2^kDeferLog2
         const bool grow = (mt - m_run) * scale_log2e > kDeferLog2;      // also true on the first tile (m_run = -inf)
         if (__builtin_amdgcn_ballot_w64(grow) != 0) {
@@ -275,6 +282,8 @@ extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64
     const int64_t nqb = (Nq + kBM - 1) / kBM;
     const int64_t total = nqb * B * H;
     FG_CHECK_ARG(total < (1ll << 30), "fg_attn_fwd_bf16: grid too large");
+    FG_CHECK_ARG((Nkv + 2 * kBN) * ldk * 2 < (1ll << 32) && (Nkv + 2 * kBN) * ldv * 2 < (1ll << 32),
+                 "fg_attn_fwd_bf16: K/V of one batch element must span < 4 GiB (32-bit buffer offsets)");
     const float scale_log2e = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)total), dim3(kThreads), 0, (hipStream_t)stream, (const bf16*)q, ldq,
                        (const bf16*)k, ldk, (const bf16*)v, ldv, (bf16*)out, Nq, Nkv, H, (int)nqb, (int)total, scale_log2e);
