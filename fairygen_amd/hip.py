@@ -9,7 +9,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfairygen_hip.so")
+# FAIRYGEN_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments); still no fallback.
+_LIB_PATH = os.environ.get("FAIRYGEN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfairygen_hip.so")
 _lib = None
 
 ABI_VERSION = 1
