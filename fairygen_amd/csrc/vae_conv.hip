@@ -1,6 +1,7 @@
 // Causal 3-D convolution of the Wan2.2 VAE decoder as an implicit GEMM on bf16 MFMA (gfx950).
 //
-// Replaces CausalConv3d.forward (models/wan_video_vae.py:33-52) incl. its feature-cache concat, and the
+// Replaces CausalConv3d.forward (models/wan_video_vae.py:33-52) incl. its feature-cache concat (the input
+// tensor simply carries its kt-1 history frames in front), and the
 // nearest-exact-2x Upsample + Conv2d pair of Resample38 (:242-251), the channel->time interleave after
 // time_conv (:153-156) and the residual add of ResidualBlock (:301).
 //
@@ -25,14 +26,14 @@ constexpr int kTile = 128 * kBK * 2;   // 16 KiB per operand tile
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 struct ConvParams {
-    const bf16* x;
-    const bf16* prev;
+    const bf16* x;          // (T + kt-1, Hin, Win, Cin): the first kt-1 frames are the causal history (feature cache)
     const bf16* wp;
     const bf16* bias;
     const bf16* residual;
     bf16* out;
     int T, H, W, Hin, Win, Cin, Cout, kt, ks, cin_pad, cout_pad, upsample, interleave;
-    int64_t M;      // T*H*W output pixels
+    int64_t M;              // T*H*W output pixels
+    uint32_t x_bytes, w_bytes;
 };
 
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
@@ -50,58 +51,87 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
     const int c0 = ctile * kBMc;
     const int64_t m0 = ptile * kBNp;
 
-    // ---- staging roles: thread moves rows (tid>>3)+32*i, chunk (tid&7) of both tiles
+    // ---- staging roles: thread moves rows (tid>>3)+32*i, 16-byte chunk (tid&7) of both tiles.
+    // Loads are bounds-checked buffer loads with 32-bit byte offsets: an out-of-range offset (spatial zero padding,
+    // pixels past M, channels past Cin) returns zeros; the weight side needs NO per-step vector arithmetic at all
+    // (loop-invariant voffset + scalar soffset).
     const int st_row = tid >> 3, st_chunk = tid & 7;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wp), 0, p.w_bytes, 0x00020000);
+    constexpr uint32_t kOOB = 0xF0000000u;      // >= x_bytes (host-checked); + the small scalar offset cannot wrap
     int pt[4], py[4], px[4];
     bool pv[4];
+    uint32_t w_off[4];
+    int st_lds[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + st_row + 32 * i;
         pv[i] = m < p.M;
-        const int64_t mm = pv[i] ? m : 0;
+        const int64_t mm = m < p.M ? m : 0;
         px[i] = (int)(mm % p.W);
         py[i] = (int)((mm / p.W) % p.H);
         pt[i] = (int)(mm / ((int64_t)p.W * p.H));
+        w_off[i] = (uint32_t)(((c0 + st_row + 32 * i) * p.cin_pad + st_chunk * 8) * 2);
+        st_lds[i] = lds_off(st_row + 32 * i, st_chunk);
     }
     const int pad = p.ks >> 1;
     const int ksteps_per_tap = p.cin_pad / kBK;
     const int ntaps = p.kt * p.ks * p.ks;
     const int nsteps = ntaps * ksteps_per_tap;
+    const uint32_t w_tap_stride = (uint32_t)(p.cout_pad * p.cin_pad * 2);
 
-    u32x4 areg[4], breg[4];
-    auto stage_load = [&](int step) {
-        const int tap = step / ksteps_per_tap;
-        const int cin0 = (step - tap * ksteps_per_tap) * kBK + st_chunk * 8;
-        const int dt = tap / (p.ks * p.ks);
-        const int dy = (tap / p.ks) % p.ks;
-        const int dx = tap % p.ks;
-        const bf16* wbase = p.wp + ((int64_t)tap * p.cout_pad + c0) * p.cin_pad + cin0;
+    // load cursor (runs one step ahead of the math): tap coordinates advance by counters, no divisions in the loop
+    int ld_dt = 0, ld_dy = 0, ld_dx = 0, ld_cs = 0;
+    uint32_t ld_wbase = 0;            // scalar byte offset of (tap, cin step) in the packed weights
+    uint32_t x_off[4];
+    auto tap_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            areg[i] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)(st_row + 32 * i) * p.cin_pad);
-            u32x4 val = {0u, 0u, 0u, 0u};
-            int yy = py[i] + dy - pad, xx = px[i] + dx - pad;
-            const int ft = pt[i] + dt - (p.kt - 1);
-            if (pv[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && cin0 < p.Cin) {
-                if (p.upsample) { yy >>= 1; xx >>= 1; }
-                const int64_t pix = (int64_t)yy * p.Win + xx;
-                const int64_t fsz = (int64_t)p.Hin * p.Win;
-                if (ft >= 0)
-                    val = *reinterpret_cast<const u32x4*>(p.x + ((int64_t)ft * fsz + pix) * p.Cin + cin0);
-                else if (p.prev != nullptr)
-                    val = *reinterpret_cast<const u32x4*>(p.prev + ((int64_t)(ft + 2) * fsz + pix) * p.Cin + cin0);
+            int yy = py[i] + ld_dy - pad, xx = px[i] + ld_dx - pad;
+            const bool ok = pv[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            if (p.upsample) { yy >>= 1; xx >>= 1; }
+            const uint32_t off = (uint32_t)((((pt[i] + ld_dt) * p.Hin + yy) * p.Win + xx) * p.Cin + st_chunk * 8) * 2u;
+            x_off[i] = ok ? off : kOOB;
+        }
+    };
+    u32x4 areg[4], breg[4];
+    auto stage_load = [&]() {
+        const uint32_t cs_bytes = (uint32_t)ld_cs * (kBK * 2);
+        const bool cin_ok = ld_cs * kBK + st_chunk * 8 < p.Cin;      // dead chunks only when Cin % 64 != 0 (zero weights there)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off[i], ld_wbase + cs_bytes, 0);
+            breg[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, cin_ok ? x_off[i] : kOOB, cs_bytes, 0);
+        }
+    };
+    auto advance = [&]() {
+        if (++ld_cs == ksteps_per_tap) {
+            ld_cs = 0;
+            ld_wbase += w_tap_stride;
+            if (++ld_dx == p.ks) {
+                ld_dx = 0;
+                if (++ld_dy == p.ks) { ld_dy = 0; ++ld_dt; }
             }
-            breg[i] = val;
+            tap_offsets();
         }
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int off = lds_off(st_row + 32 * i, st_chunk);
-            *reinterpret_cast<u32x4*>(a_lds + buf * kTile + off) = areg[i];
-            *reinterpret_cast<u32x4*>(b_lds + buf * kTile + off) = breg[i];
+            *reinterpret_cast<u32x4*>(a_lds + buf * kTile + st_lds[i]) = areg[i];
+            *reinterpret_cast<u32x4*>(b_lds + buf * kTile + st_lds[i]) = breg[i];
         }
     };
+
+    // loop-invariant fragment read addresses
+    int a_rd[2][4], b_rd[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_rd[i][ks] = lds_off(wm * 64 + i * 32 + r, 2 * ks + hh);
+            b_rd[i][ks] = lds_off(wn * 64 + i * 32 + r, 2 * ks + hh);
+        }
 
     f32x16 acc[2][2];   // [cout sub-tile mi][pixel sub-tile ni]
 #pragma unroll
@@ -111,14 +141,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
-    stage_load(0);
+    tap_offsets();
+    stage_load();
     stage_write(0);
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        const bool has_next = step + 1 < nsteps;
-        if (has_next) stage_load(step + 1);
+        const bool has_next = step + 1 < nsteps;      // wave-uniform
+        if (has_next) {
+            advance();
+            stage_load();
+        }
         const char* ab = a_lds + cur * kTile;
         const char* bb = b_lds + cur * kTile;
 #pragma unroll
@@ -126,8 +160,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
             bf16x8 af[2], bfg[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(ab + lds_off(wm * 64 + i * 32 + r, 2 * ks + hh));
-                bfg[i] = *reinterpret_cast<const bf16x8*>(bb + lds_off(wn * 64 + i * 32 + r, 2 * ks + hh));
+                af[i] = *reinterpret_cast<const bf16x8*>(ab + a_rd[i][ks]);
+                bfg[i] = *reinterpret_cast<const bf16x8*>(bb + b_rd[i][ks]);
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -212,27 +246,29 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
     return fg_launch_status("fg_conv_pack_weight_bf16");
 }
 
-int fg_conv3d_cl_bf16(const void* x, const void* prev, const void* w_packed, const void* bias, const void* residual,
-                      void* out, int T, int H, int W, int Cin, int Cout, int kt, int ks, int upsample2x,
-                      int time_interleave, fg_stream_t stream) {
+int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, const void* residual, void* out, int T, int H,
+                      int W, int Cin, int Cout, int kt, int ks, int upsample2x, int time_interleave, fg_stream_t stream) {
     FG_CHECK_ARG(x && w_packed && bias && out, "fg_conv3d_cl_bf16: null pointer");
     FG_CHECK_ARG(T > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "fg_conv3d_cl_bf16: sizes must be positive");
     FG_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "fg_conv3d_cl_bf16: kt and ks must be 1 or 3");
-    FG_CHECK_ARG(Cin % 8 == 0 && Cout % 4 == 0, "fg_conv3d_cl_bf16: Cin %% 8 and Cout %% 4 must be 0 (Cin=%d Cout=%d)", Cin, Cout);
+    FG_CHECK_ARG(Cin % 8 == 0 && Cout % 4 == 0, "fg_conv3d_cl_bf16: need Cin %% 8 == 0 and Cout %% 4 == 0 (Cin=%d Cout=%d)", Cin, Cout);
     FG_CHECK_ARG(!upsample2x || (H % 2 == 0 && W % 2 == 0 && kt == 1), "fg_conv3d_cl_bf16: upsample2x needs even H, W and kt==1");
     FG_CHECK_ARG(!time_interleave || (Cout % 8 == 0), "fg_conv3d_cl_bf16: time_interleave needs Cout %% 8 == 0");
-    FG_CHECK_ARG(prev == nullptr || kt == 3, "fg_conv3d_cl_bf16: a feature cache only makes sense with kt == 3");
-    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(prev) && FG_ALIGNED16(w_packed) && ((uintptr_t)bias & 7) == 0 &&
-                     ((uintptr_t)residual & 7) == 0 && ((uintptr_t)out & 7) == 0,
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(w_packed) && ((uintptr_t)bias & 7) == 0 && ((uintptr_t)residual & 7) == 0 &&
+                     ((uintptr_t)out & 7) == 0,
                  "fg_conv3d_cl_bf16: misaligned pointer");
     ConvParams p;
-    p.x = (const bf16*)x; p.prev = (const bf16*)prev; p.wp = (const bf16*)w_packed; p.bias = (const bf16*)bias;
+    p.x = (const bf16*)x; p.wp = (const bf16*)w_packed; p.bias = (const bf16*)bias;
     p.residual = (const bf16*)residual; p.out = (bf16*)out;
     p.T = T; p.H = H; p.W = W; p.Hin = upsample2x ? H / 2 : H; p.Win = upsample2x ? W / 2 : W;
     p.Cin = Cin; p.Cout = Cout; p.kt = kt; p.ks = ks;
     p.cin_pad = roundup(Cin, kBK); p.cout_pad = roundup(Cout, kBMc);
     p.upsample = upsample2x ? 1 : 0; p.interleave = time_interleave ? 1 : 0;
     p.M = (int64_t)T * H * W;
+    const int64_t x_bytes = (int64_t)(T + kt - 1) * p.Hin * p.Win * Cin * 2;
+    const int64_t w_bytes = fg_conv_packed_bytes(Cout, Cin, kt, ks, ks);
+    FG_CHECK_ARG(x_bytes < 0xF0000000ll && w_bytes < 0xF0000000ll, "fg_conv3d_cl_bf16: input / weights must be < 3.75 GiB (32-bit offsets)");
+    p.x_bytes = (uint32_t)x_bytes; p.w_bytes = (uint32_t)w_bytes;
     const int64_t blocks = ((p.M + kBNp - 1) / kBNp) * (p.cout_pad / kBMc);
     FG_CHECK_ARG(blocks < (1ll << 31), "fg_conv3d_cl_bf16: grid too large");
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);

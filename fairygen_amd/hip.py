@@ -29,7 +29,7 @@ _SIGNATURES = {
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "fg_conv_pack_weight_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "fg_conv3d_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_conv3d_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "fg_dupup3d_add_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "fg_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i64, _f32, _vp],
     "fg_vae_latent_to_cl_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -275,23 +275,20 @@ def conv_pack_weight(w):
     return packed
 
 
-def conv3d_cl(x, w_packed, bias, cout, kt, ks, prev=None, residual=None, upsample2x=False, time_interleave=False,
-              out=None):
-    """x (T,Hin,Win,Cin) channels-last -> (T,H,W,Cout) [or (2T,H,W,Cout/2) with time_interleave]."""
+def conv3d_cl(x, w_packed, bias, cout, kt, ks, residual=None, upsample2x=False, time_interleave=False, out=None):
+    """x (T + kt-1, Hin, Win, Cin) channels-last, the first kt-1 frames being the causal history (feature cache)
+    -> (T,H,W,Cout) [or (2T,H,W,Cout/2) with time_interleave]."""
     _dev(x, "x"), _dev(w_packed, "w_packed"), _dev(bias, "bias")
-    assert x.dim() == 4 and x.is_contiguous()
-    t, hin, win, cin = x.shape
+    assert x.dim() == 4 and x.is_contiguous() and x.shape[0] > kt - 1
+    t, hin, win, cin = x.shape[0] - (kt - 1), x.shape[1], x.shape[2], x.shape[3]
     h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
     oshape = (2 * t, h, w, cout // 2) if time_interleave else (t, h, w, cout)
     out = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else out
     assert tuple(out.shape) == oshape and out.is_contiguous()
-    if prev is not None:
-        _dev(prev, "prev")
-        assert tuple(prev.shape) == (2, hin, win, cin) and prev.is_contiguous()
     if residual is not None:
         _dev(residual, "residual")
         assert tuple(residual.shape) == oshape and residual.is_contiguous()
-    _call("fg_conv3d_cl_bf16", _ptr(x), _ptr(prev), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(out), t, h, w,
+    _call("fg_conv3d_cl_bf16", _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(out), t, h, w,
           cin, cout, kt, ks, int(upsample2x), int(time_interleave), _stream(x))
     return out
 

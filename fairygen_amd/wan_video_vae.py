@@ -152,18 +152,34 @@ class Decoder3d_38(nn.Module):
 
 
 class _ConvState:
-    """Packed weight + zero-initialised 2-frame feature cache of one conv for one decode."""
+    """Packed weight of one conv + (for causal 3x3x3 / 3x1x1 convs) its input ring for one decode:
+    ring[0:2] = the feature cache (the previous two input frames, zeros at the start), ring[2:2+T] = the chunk's
+    input, written in place by the producer kernel, so the conv reads one contiguous (T+2,H,W,C) tensor."""
 
-    __slots__ = ("packed", "bias", "cout", "kt", "ks", "cache")
+    __slots__ = ("packed", "bias", "cout", "cin", "kt", "ks", "ring")
 
     def __init__(self, conv):
         w = conv.weight
         self.packed = hip.conv_pack_weight(w)
         self.bias = conv.bias.contiguous()
-        self.cout = w.shape[0]
+        self.cout, self.cin = w.shape[0], w.shape[1]
         self.kt = w.shape[2] if w.dim() == 5 else 1
         self.ks = w.shape[-1]
-        self.cache = None
+        self.ring = None
+
+    def slot(self, t, h, w, dtype, device):
+        """View (t,h,w,cin) of the ring where the producer writes this chunk's input."""
+        if self.ring is None or self.ring.shape[0] < t + CACHE_T or tuple(self.ring.shape[1:3]) != (h, w):
+            old = self.ring
+            self.ring = torch.zeros((t + CACHE_T, h, w, self.cin), dtype=dtype, device=device)
+            if old is not None and tuple(old.shape[1:3]) == (h, w):
+                self.ring[:CACHE_T].copy_(old[:CACHE_T])
+        return self.ring[CACHE_T:CACHE_T + t]
+
+    def shift(self, t):
+        """After the conv: the last two frames of [cache; chunk] become the cache (wan_video_vae.py:288-297)."""
+        self.ring[0].copy_(self.ring[t])
+        self.ring[1].copy_(self.ring[t + 1])
 
 
 class VideoVAE38_(nn.Module):
@@ -204,30 +220,33 @@ class VideoVAE38_(nn.Module):
         return self._conv_states
 
     # ------------------------------------------------------------------ building blocks (channels-last)
-    def _conv(self, conv, x, cached=False, residual=None, upsample2x=False, time_interleave=False):
+    def _conv(self, conv, x, residual=None, upsample2x=False, time_interleave=False):
+        """Conv without temporal extent (1x1x1 shortcut, conv2, the 3x3 Conv2d after upsampling)."""
         st = self._states()[id(conv)]
-        prev = None
-        if cached and st.kt == 3:
-            if st.cache is None:
-                st.cache = torch.zeros((CACHE_T,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            prev = st.cache
-        y = hip.conv3d_cl(x, st.packed, st.bias, st.cout, st.kt, st.ks, prev=prev, residual=residual,
-                          upsample2x=upsample2x, time_interleave=time_interleave)
-        if prev is not None:        # shift the chunk's frames into the ring (wan_video_vae.py:288-297)
-            if x.shape[0] >= CACHE_T:
-                prev.copy_(x[-CACHE_T:])
-            else:
-                prev[0].copy_(prev[1])
-                prev[1].copy_(x[0])
+        return hip.conv3d_cl(x, st.packed, st.bias, st.cout, st.kt, st.ks, residual=residual, upsample2x=upsample2x,
+                             time_interleave=time_interleave)
+
+    def _slot(self, conv, like, t=None):
+        """Where the producer of `conv`'s input must write: a (T,H,W,Cin) view inside the conv's ring."""
+        st = self._states()[id(conv)]
+        return st.slot(like.shape[0] if t is None else t, like.shape[1], like.shape[2], like.dtype, like.device)
+
+    def _cconv(self, conv, t, residual=None, time_interleave=False):
+        """Causal conv over [feature cache; chunk] (its input was written into the ring slot), then roll the cache."""
+        st = self._states()[id(conv)]
+        y = hip.conv3d_cl(st.ring[: t + CACHE_T], st.packed, st.bias, st.cout, st.kt, st.ks, residual=residual,
+                          time_interleave=time_interleave)
+        st.shift(t)
         return y
 
     def _res(self, blk, x):
         r = blk.residual
+        t = x.shape[0]
         h = x if isinstance(blk.shortcut, nn.Identity) else self._conv(blk.shortcut, x)
-        y = hip.vae_rmsnorm_silu(x, r[0].gamma.view(-1), True)
-        y = self._conv(r[2], y, cached=True)
-        y = hip.vae_rmsnorm_silu(y, r[3].gamma.view(-1), True)
-        return self._conv(r[6], y, cached=True, residual=h)
+        hip.vae_rmsnorm_silu(x, r[0].gamma.view(-1), True, out=self._slot(r[2], x))
+        y = self._cconv(r[2], t)
+        hip.vae_rmsnorm_silu(y, r[3].gamma.view(-1), True, out=self._slot(r[6], y))
+        return self._cconv(r[6], t, residual=h)
 
     def _attn(self, blk, x):
         t, hh, ww, c = x.shape
@@ -243,12 +262,14 @@ class VideoVAE38_(nn.Module):
 
     def _resample_up(self, rs, x, first_chunk):
         if rs.mode == "upsample3d" and not first_chunk:      # first chunk: 'Rep', no temporal doubling (:125-127)
-            x = self._conv(rs.time_conv, x, cached=True, time_interleave=True)
+            self._slot(rs.time_conv, x).copy_(x)
+            x = self._cconv(rs.time_conv, x.shape[0], time_interleave=True)
         return self._conv(rs.resample[1], x, upsample2x=True)
 
     def _decoder_chunk(self, x, first_chunk):
         dec = self.decoder
-        x = self._conv(dec.conv1, x, cached=True)
+        self._slot(dec.conv1, x).copy_(x)
+        x = self._cconv(dec.conv1, x.shape[0])
         x = self._res(dec.middle[0], x)
         x = self._attn(dec.middle[1], x)
         x = self._res(dec.middle[2], x)
@@ -263,13 +284,13 @@ class VideoVAE38_(nn.Module):
                 x = hip.dupup3d_add(x, main, sc.out_channels, sc.factor_t, sc.factor_s, first_chunk)
             else:
                 x = main
-        x = hip.vae_rmsnorm_silu(x, dec.head[0].gamma.view(-1), True)
-        return self._conv(dec.head[2], x, cached=True)
+        hip.vae_rmsnorm_silu(x, dec.head[0].gamma.view(-1), True, out=self._slot(dec.head[2], x))
+        return self._cconv(dec.head[2], x.shape[0])
 
     def clear_cache(self):
         if self._conv_states is not None:
             for st in self._conv_states.values():
-                st.cache = None
+                st.ring = None
 
     def decode(self, z, scale, clamp=False):
         """z (1,48,T,h,w) on the HIP device -> (1,3,4T-3,16h,16w) (reference :1326-1351)."""

@@ -115,13 +115,14 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
 
 /* Causal conv as implicit GEMM on MFMA: CausalConv3d.forward models/wan_video_vae.py:33-52 (kt in {1,3},
  * kh==kw in {1,3}, stride 1, "same" spatial zero padding, causal time padding) and the Conv2d after
- * nearest-exact 2x upsampling in Resample38 (:242-251) when upsample2x!=0 (input is (T,H/2,W/2,Cin)).
- * prev: the layer's feature cache = the previous 2 input frames (2,Hin,Win,Cin), or NULL for zeros
- * (first chunk / 'Rep').  out (T,H,W,Cout), or with time_interleave!=0 (Resample.forward :153-156,
+ * nearest-exact 2x upsampling in Resample38 (:242-251) when upsample2x!=0 (input is (.,H/2,W/2,Cin)).
+ * x: (T + kt-1, Hin, Win, Cin) — the first kt-1 frames are the layer's feature cache, i.e. the previous input
+ * frames that the reference concatenates in front (:46-49), zeros on the first chunk / after 'Rep'; output frame
+ * t reads input frames t .. t+kt-1.  out (T,H,W,Cout), or with time_interleave!=0 (Resample.forward :153-156,
  * Cout = 2*Cout2): out (2T,H,W,Cout2) with channel block j of frame t written to frame 2t+j.
- * residual (same shape as out, or NULL) is added after the bf16 rounding of conv+bias (ResidualBlock
- * :301). */
-int fg_conv3d_cl_bf16(const void* x, const void* prev, const void* w_packed, const void* bias,
+ * residual (same shape as out, or NULL) is added after the bf16 rounding of conv+bias (ResidualBlock :301).
+ * Cin % 8 == 0; Cout % 4 == 0; input and packed weights < 3.75 GiB each (32-bit buffer offsets). */
+int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias,
                       const void* residual, void* out,
                       int T, int H, int W, int Cin, int Cout, int kt, int ks,
                       int upsample2x, int time_interleave, fg_stream_t stream);

@@ -193,7 +193,8 @@ def test_conv3d_cl(hip, cin, cout, kt, ks, T, H, W, cache):
     sd32 = {k: v.float() for k, v in sd.items()}
     ref32 = wan_vae.causal_conv3d(sd32, "c", x.float(), None if prev is None else prev.float())
     packed = hip.conv_pack_weight(dev(w))
-    got = hip.conv3d_cl(dev(_cl(x)), packed, dev(b), cout, kt, ks, prev=None if prev is None else dev(_cl(prev)))
+    xin = x if kt == 1 else torch.cat([prev if prev is not None else torch.zeros_like(x[:, :, :1]).expand(-1, -1, 2, -1, -1), x], dim=2)
+    got = hip.conv3d_cl(dev(_cl(xin)), packed, dev(b), cout, kt, ks)
     got = _ncthw(got.cpu()).float()
     err_ref, err = (ref16 - ref32).abs().max().item(), (got - ref32).abs().max().item()
     assert err <= 2 * err_ref + 1e-3, f"conv err {err} vs reference-bf16 err {err_ref}"
@@ -216,7 +217,7 @@ def test_conv_upsample_interleave_residual(hip):
     t = wan_vae.causal_conv3d({"c.weight": wt, "c.bias": bt}, "c", x, prev)
     t = t.reshape(1, 2, c, 2, 5, 6)
     want = torch.stack((t[:, 0], t[:, 1]), 3).reshape(1, c, 4, 5, 6)
-    got = hip.conv3d_cl(dev(_cl(x)), hip.conv_pack_weight(dev(wt)), dev(bt), 2 * c, 3, 1, prev=dev(_cl(prev)), time_interleave=True)
+    got = hip.conv3d_cl(dev(_cl(torch.cat([prev, x], dim=2))), hip.conv_pack_weight(dev(wt)), dev(bt), 2 * c, 3, 1, time_interleave=True)
     assert (_ncthw(got.cpu()).float() - want.float()).abs().max().item() < 3e-2
 
 

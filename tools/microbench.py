@@ -56,13 +56,12 @@ def main():
         fl = 4.0 * a.nq * a.nkv * c
         print(f"attn nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
     elif a.what == "conv":
-        x = rnd(a.t, a.h, a.w, a.cin)
+        x = rnd(a.t + a.kt - 1, a.h, a.w, a.cin)
         w = rnd(a.cout, a.cin, a.kt, a.ks, a.ks) * (a.cin * a.kt * a.ks * a.ks) ** -0.5
         b = rnd(a.cout)
-        prev = rnd(2, a.h, a.w, a.cin) if a.kt == 3 else None
         wp = hip.conv_pack_weight(w)
         out = torch.empty((a.t, a.h, a.w, a.cout), dtype=torch.bfloat16, device=dev)
-        med, mn = timeit(lambda: hip.conv3d_cl(x, wp, b, a.cout, a.kt, a.ks, prev=prev, out=out), a.iters)
+        med, mn = timeit(lambda: hip.conv3d_cl(x, wp, b, a.cout, a.kt, a.ks, out=out), a.iters)
         fl = 2.0 * a.t * a.h * a.w * a.cout * a.cin * a.kt * a.ks * a.ks
         print(f"conv {a.cin}->{a.cout} k=({a.kt},{a.ks},{a.ks}) @({a.t},{a.h},{a.w}): median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms")
     else:
