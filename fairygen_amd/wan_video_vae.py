@@ -194,6 +194,7 @@ class VideoVAE38_(nn.Module):
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d_38(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._conv_states = None
+        self.max_chunk_group = 4      # latent frames per decoder call after the first (1 = the reference's chunking)
 
     # ------------------------------------------------------------------ weight preparation
     def invalidate_packed(self):
@@ -302,11 +303,19 @@ class VideoVAE38_(nn.Module):
         x = self._conv(self.conv2, x)
         frames = 4 * T - 3
         video = torch.empty((3, frames, 16 * h, 16 * w), dtype=z.dtype, device=z.device)
-        t0 = 0
-        for i in range(T):
-            out = self._decoder_chunk(x[i:i + 1], first_chunk=(i == 0))
+        # The reference decodes one latent frame per decoder call (:1337-1348).  Every op after the first chunk is
+        # causal in time with the 2-frame feature cache, so latent frames 1.. can go through the decoder in groups
+        # with identical arithmetic per output; larger groups fill the chip on the low-resolution layers.  The
+        # group is bounded by the 32-bit byte offsets of the conv kernel (largest ring: (4G+2, 8h, 8w, widest C)).
+        widest = max(st.cin for st in self._states().values())
+        group = int(max(1, min(self.max_chunk_group, (3.5e9 / (8 * h * 8 * w * min(widest, 512) * 2) - 2) // 4)))
+        t0, i = 0, 0
+        while i < T:
+            n = 1 if i == 0 else min(group, T - i)
+            out = self._decoder_chunk(x[i:i + n], first_chunk=(i == 0))
             hip.vae_unpatchify(out, video, t0, clamp)
             t0 += out.shape[0]
+            i += n
         assert t0 == frames
         self.clear_cache()
         return video.unsqueeze(0)
