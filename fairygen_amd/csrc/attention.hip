@@ -23,6 +23,9 @@
 //   * workgroup -> (head, q-block) map is XCD-aware: the 8 XCDs each walk a contiguous range of heads, so
 //     the 32 CUs sharing an L2 stream the SAME head's K/V at the same time.
 #include "common.h"
+#include <math.h>
+#include <queue>
+#include <vector>
 
 #ifndef FG_EXP
 #define FG_EXP 0      // timing-only experiments (wrong results): 1 no barrier, 2 no LDS reads, 3 no softmax VALU
@@ -64,10 +67,27 @@ __device__ __forceinline__ float pair_sum(float x) {
 // WAVES waves per workgroup, each owning QB blocks of 32 query rows (WAVES*QB*32 == 256):
 //   <8,1>: two waves per SIMD, 32 rows each (<= 256 VGPRs);  <4,2>: one wave per SIMD with the whole 512-register
 //   file, 64 rows each -- every K / V^T fragment read from LDS feeds two MFMAs (half the LDS traffic per FLOP).
+// Work decomposition (host-chosen, see choose_split): per (batch, head) the first `nfull` q-blocks are "direct" workgroups
+// over the whole KV range; the last `R` q-blocks are each cut into `S` KV ranges ("pieces") whose un-normalised
+// partial O / running max / row sum go to the workspace and are merged by attn_combine_kernel.  Direct workgroups get
+// the low block ids (dispatched first), the small pieces fill the tail: wave quantisation (2568 workgroups on 256 CUs
+// = 10.03 rounds at N = 27 280; 336 = 1.31 rounds for a 1/8 token shard) costs a fraction of a piece instead of a round.
+struct AttnParams {
+    const bf16* q; const bf16* k; const bf16* v; bf16* out;
+    int64_t ldq, ldk, ldv, Nq, Nkv;
+    int H, nqb, nfull, R, S, total_direct;
+    float scale_log2e;
+    float* o_part;      // [piece][256][128] fp32
+    float* ml_part;     // [piece][256][2]   (running max in raw score units, row sum)
+};
+
 template <int WAVES, int QB>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kernel(
-    const bf16* __restrict__ q, int64_t ldq, const bf16* __restrict__ k, int64_t ldk, const bf16* __restrict__ v,
-    int64_t ldv, bf16* __restrict__ out, int64_t Nq, int64_t Nkv, int H, int nqb, int total_blocks, float scale_log2e) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kernel(const AttnParams P) {
+    const bf16* __restrict__ q = P.q; const bf16* __restrict__ k = P.k; const bf16* __restrict__ v = P.v;
+    bf16* __restrict__ out = P.out;
+    const int64_t ldq = P.ldq, ldk = P.ldk, ldv = P.ldv, Nq = P.Nq, Nkv = P.Nkv;
+    const int H = P.H;
+    const float scale_log2e = P.scale_log2e;
     static_assert(WAVES * QB * 32 == kBM, "workgroup covers 256 query rows");
     constexpr int THREADS = WAVES * 64;
     constexpr int NST = (kBN * 16) / THREADS;      // 16-byte chunks per thread per tile (2 or 4)
@@ -76,15 +96,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
     char* const k_lds = smem;
     char* const v_lds = smem + 2 * kTileBytes;
 
-    // ---- XCD-aware block remap: blocks b and b+8 share an XCD; give each XCD a contiguous logical range.
-    int logical;
-    {
+    const int nt = (int)((Nkv + kBN - 1) / kBN);
+    int qb, bh, t_begin = 0, t_end = nt, piece = -1;
+    if ((int)blockIdx.x < P.total_direct) {
+        // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous logical range (of heads).
         const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
-        const int qd = total_blocks >> 3, rm = total_blocks & 7;
-        logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+        const int qd = P.total_direct >> 3, rm = P.total_direct & 7;
+        const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+        qb = logical % P.nfull;
+        bh = logical / P.nfull;      // b*H + h
+    } else {
+        piece = (int)blockIdx.x - P.total_direct;
+        const int sp = piece % P.S, rq = (piece / P.S) % P.R;
+        bh = piece / (P.S * P.R);
+        qb = P.nfull + rq;
+        t_begin = (int)((int64_t)sp * nt / P.S);
+        t_end = (int)((int64_t)(sp + 1) * nt / P.S);
     }
-    const int qb = logical % nqb;
-    const int bh = logical / nqb;      // b*H + h
     const int b = bh / H, h = bh % H;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +139,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
 
     // ---- tile staging: thread t moves rows (t>>4) + ST_ROWS*i, 16-byte chunk (t&15), of K and V.
     const int st_row = tid >> 4, st_chunk = tid & 15;
-    const int nt = (int)((Nkv + kBN - 1) / kBN);
     int st_k[NST], st_v[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
@@ -208,7 +235,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
 
     // One pipeline step for tile t: sc = scores(t) (ready), sn <- scores(t+1) while softmax(sc) runs, then PV(t).
     auto step = [&](f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2], int t) {
-        const int cur = t & 1;
+        const int cur = (t - t_begin) & 1;
         load_k(t + 2);
         load_v(t + 1);
 
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
         // K(t+2) replaces K(t) (last read in step t-1), V(t+1) replaces V(t-1) (last read in step t-1)
         write_k(cur);
         write_v(cur ^ 1);
-        if ((int64_t)(t + 2) * kBN > Nkv && t + 1 < nt) mask_tile(sn, t + 1);      // ragged last tile (wave-uniform)
+        if ((int64_t)(t + 2) * kBN > Nkv && t + 1 < t_end) mask_tile(sn, t + 1);   // ragged last tile (wave-uniform)
 #if FG_EXP != 1
         __syncthreads();
 #endif
@@ -284,41 +311,165 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
 
     // ---- prologue: K(0), V(0), K(1) resident; scores(0) computed
     f32x16 sA[QB][2], sB[QB][2];
-    load_k(0);
-    load_v(0);
+    load_k(t_begin);
+    load_v(t_begin);
     write_k(0);
     write_v(0);
-    load_k(1);
+    load_k(t_begin + 1);
     write_k(1);
     __syncthreads();
     qk_tile(sA, 0);
-    if ((int64_t)kBN > Nkv) mask_tile(sA, 0);
-    __syncthreads();      // every wave is done with K(0) before step 0 overwrites it with K(2)
+    if ((int64_t)(t_begin + 1) * kBN > Nkv) mask_tile(sA, t_begin);
+    __syncthreads();      // every wave is done with the first K tile before step 0 overwrites it
 
-    int t = 0;
-    for (; t + 1 < nt; t += 2) {
+    int t = t_begin;
+    for (; t + 1 < t_end; t += 2) {
         step(sA, sB, t);
         step(sB, sA, t + 1);
     }
-    if (t < nt) step(sA, sB, t);
+    if (t < t_end) step(sA, sB, t);
 
-    // ---- epilogue: normalise and store O[query r][d = 32db + 8g + 4hh + 0..3]
+    // ---- epilogue: lane holds O[query r][d = 32db + 8g + 4hh + 0..3]
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
-        const float inv = 1.0f / pair_sum(l_run[qi]);
-        if (q_valid[qi]) {
-            bf16* orow = op + my_q[qi] * ((int64_t)H * kD);
+        const float l_tot = pair_sum(l_run[qi]);
+        if (piece < 0) {      // direct: normalise and store bf16
+            const float inv = 1.0f / l_tot;
+            if (q_valid[qi]) {
+                bf16* orow = op + my_q[qi] * ((int64_t)H * kD);
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 w4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = (bf16)(o[qi][db][4 * g + j] * inv);
+                        *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g + 4 * hh) = w4;
+                    }
+            }
+        } else {              // piece: un-normalised partial + (max, sum) to the workspace
+            const int row = (wave * QB + qi) * 32 + r;
+            float* orow = P.o_part + ((int64_t)piece * kBM + row) * kD;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bf16x4 w4;
+                    f32x4 w4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w4[j] = (bf16)(o[qi][db][4 * g + j] * inv);
-                    *reinterpret_cast<bf16x4*>(orow + 32 * db + 8 * g + 4 * hh) = w4;
+                    for (int j = 0; j < 4; ++j) w4[j] = o[qi][db][4 * g + j];
+                    *reinterpret_cast<f32x4*>(orow + 32 * db + 8 * g + 4 * hh) = w4;
                 }
+            if (hh == 0) {
+                float* ml = P.ml_part + ((int64_t)piece * kBM + row) * 2;
+                ml[0] = m_run[qi];
+                ml[1] = l_tot;
+            }
         }
     }
+}
+
+// Merge the S partials of every split q-block: out = sum_s w_s O_s / sum_s w_s l_s, w_s = 2^((m_s - max m) * scale*log2e).
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams P) {
+    const int blk = blockIdx.x;                // (bh, rq)
+    const int rq = blk % P.R, bh = blk / P.R;
+    const int b = bh / P.H, h = bh % P.H;
+    const int qb = P.nfull + rq;
+    const int lane32 = threadIdx.x & 31, rsub = threadIdx.x >> 5;      // 8 rows per pass, one float4 of d per lane
+    const int64_t piece0 = ((int64_t)bh * P.R + rq) * P.S;
+    for (int row = rsub; row < kBM; row += 8) {
+        const int64_t qrow = (int64_t)qb * kBM + row;
+        if (qrow >= P.Nq) break;
+        float mmax = -INFINITY;
+        for (int sp = 0; sp < P.S; ++sp) mmax = fmaxf(mmax, P.ml_part[((piece0 + sp) * kBM + row) * 2]);
+        float denom = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < P.S; ++sp) {
+            const float* ml = P.ml_part + ((piece0 + sp) * kBM + row) * 2;
+            const float w = fast_exp2((ml[0] - mmax) * P.scale_log2e);
+            denom += w * ml[1];
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(P.o_part + ((piece0 + sp) * kBM + row) * kD + lane32 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += w * ov[j];
+        }
+        const float inv = 1.0f / denom;
+        bf16x4 w4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w4[j] = (bf16)(acc[j] * inv);
+        *reinterpret_cast<bf16x4*>(P.out + ((int64_t)b * P.Nq + qrow) * ((int64_t)P.H * kD) + (int64_t)h * kD + lane32 * 4) = w4;
+    }
+}
+
+// ---- host-side choice of (R, S): greedy list-scheduling estimate of the makespan on `cus` compute units
+struct SplitChoice { int R, S; int64_t ws_bytes; double makespan; };
+
+static double simulate_makespan(int64_t n_direct, int64_t n_pieces, double piece_cost, int cus) {
+    // Greedy list scheduling in dispatch order: unit-cost direct workgroups first, then the pieces.
+    const int64_t full = n_direct / cus, rem = n_direct % cus;
+    if (n_pieces == 0) return (double)(full + (rem ? 1 : 0));
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < cus; ++i) free_at.push((double)(full + (i < rem ? 1 : 0)));
+    double last = (double)(full + (rem ? 1 : 0));
+    for (int64_t i = 0; i < n_pieces; ++i) {
+        const double t = free_at.top() + piece_cost;
+        free_at.pop();
+        free_at.push(t);
+        last = t > last ? t : last;
+    }
+    return last;
+}
+
+static SplitChoice choose_split_uncached(int B, int64_t Nq, int64_t Nkv, int H, int cus, int64_t ws_limit) {
+    const int64_t nqb = (Nq + kBM - 1) / kBM, bh = (int64_t)B * H;
+    const int nt = (int)((Nkv + kBN - 1) / kBN);
+    const int64_t per_piece = (int64_t)kBM * kD * 4 + (int64_t)kBM * 2 * 4;
+    SplitChoice best{0, 1, 0, simulate_makespan(bh * nqb, 0, 0.0, cus)};
+    const double base = best.makespan;
+    const int s_list[] = {2, 3, 4, 5, 6, 8, 12, 16};
+    for (int mode = 0; mode < 2; ++mode) {      // 0: split only the last q-block of every head; 1: split every q-block
+        const int64_t R = mode == 0 ? 1 : nqb;
+        if (mode == 0 && nqb < 2) continue;
+        if (mode == 1 && bh * nqb > 4 * (int64_t)cus) continue;      // many blocks: only the tail needs balancing
+        for (int S : s_list) {
+            if (S * 8 > nt) break;      // at least 8 KV tiles per piece, or the prologue / merge dominates
+            const int64_t pieces = bh * R * S;
+            const int64_t ws = pieces * per_piece;
+            if (ws > ws_limit) continue;
+            // a piece costs its share of the KV range plus prologue/epilogue (~3 KV tiles) plus its share of the merge
+            const double cost = 1.0 / S + 3.0 / nt + 0.004;
+            const double ms = simulate_makespan(bh * (nqb - R), pieces, cost, cus);
+            if (ms < best.makespan) best = SplitChoice{(int)R, S, ws, ms};
+        }
+    }
+    if (best.makespan > 0.98 * base) best = SplitChoice{0, 1, 0, base};      // not worth a second launch
+    return best;
+}
+
+// memo of a pure function (shapes repeat thousands of times per clip)
+static SplitChoice choose_split(int B, int64_t Nq, int64_t Nkv, int H, int cus, int64_t ws_limit) {
+    struct Key { int B, H, cus; int64_t Nq, Nkv, ws; SplitChoice val; };
+    static thread_local Key memo[8];
+    static thread_local int next = 0, filled = 0;
+    for (int i = 0; i < filled; ++i) {
+        const Key& e = memo[i];
+        if (e.B == B && e.H == H && e.cus == cus && e.Nq == Nq && e.Nkv == Nkv && e.ws == ws_limit) return e.val;
+    }
+    const SplitChoice val = choose_split_uncached(B, Nq, Nkv, H, cus, ws_limit);
+    memo[next] = Key{B, H, cus, Nq, Nkv, ws_limit, val};
+    next = (next + 1) % 8;
+    if (filled < 8) ++filled;
+    return val;
+}
+
+static int device_cus() {
+    static thread_local int cached_dev = -1, cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached_cus = n;
+        cached_dev = dev;
+    }
+    return cached_cus;
 }
 
 }  // namespace
@@ -327,9 +478,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
 #define FG_ATTN_VARIANT 8      // 8: <8 waves, 1 q-block>; 4: <4 waves, 2 q-blocks>
 #endif
 
+extern "C" int64_t fg_attn_workspace_bytes(int B, int64_t Nq, int64_t Nkv, int H) {
+    if (B <= 0 || Nq <= 0 || Nkv <= 0 || H <= 0) return 0;
+    return choose_split(B, Nq, Nkv, H, device_cus(), (int64_t)1 << 40).ws_bytes;
+}
+
+extern "C" int fg_attn_split_choice(int B, int64_t Nq, int64_t Nkv, int H, int64_t workspace_bytes, int* R, int* S) {
+    FG_CHECK_ARG(B > 0 && Nq > 0 && Nkv > 0 && H > 0 && R && S, "fg_attn_split_choice: bad arguments");
+    const SplitChoice sc = choose_split(B, Nq, Nkv, H, device_cus(), workspace_bytes);
+    *R = sc.R;
+    *S = sc.S;
+    return FG_OK;
+}
+
 extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                                void* out, int B, int64_t Nq, int64_t Nkv, int H, int D, float scale,
-                                fg_stream_t stream) {
+                                void* out, int B, int64_t Nq, int64_t Nkv, int H, int D, float scale, void* workspace,
+                                int64_t workspace_bytes, fg_stream_t stream) {
     FG_CHECK_ARG(q && k && v && out, "fg_attn_fwd_bf16: null pointer");
     FG_CHECK_ARG(D == kD, "fg_attn_fwd_bf16: only head_dim 128 is supported (got %d)", D);
     FG_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nkv > 0, "fg_attn_fwd_bf16: B, H, Nq, Nkv must be positive");
@@ -337,20 +501,32 @@ extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64
     const int64_t hd = (int64_t)H * D;
     FG_CHECK_ARG(ldq >= hd && ldk >= hd && ldv >= hd && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0,
                  "fg_attn_fwd_bf16: leading dimensions must be >= H*D and multiples of 8");
-    FG_CHECK_ARG(FG_ALIGNED16(q) && FG_ALIGNED16(k) && FG_ALIGNED16(v) && FG_ALIGNED16(out),
+    FG_CHECK_ARG(FG_ALIGNED16(q) && FG_ALIGNED16(k) && FG_ALIGNED16(v) && FG_ALIGNED16(out) && FG_ALIGNED16(workspace),
                  "fg_attn_fwd_bf16: pointers must be 16-byte aligned");
+    FG_CHECK_ARG(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "fg_attn_fwd_bf16: bad workspace");
     const int64_t nqb = (Nq + kBM - 1) / kBM;
-    const int64_t total = nqb * B * H;
-    FG_CHECK_ARG(total < (1ll << 30), "fg_attn_fwd_bf16: grid too large");
     FG_CHECK_ARG((Nkv + 2 * kBN) * ldk * 2 < (1ll << 32) && (Nkv + 2 * kBN) * ldv * 2 < (1ll << 32),
                  "fg_attn_fwd_bf16: K/V of one batch element must span < 4 GiB (32-bit buffer offsets)");
-    const float scale_log2e = scale * 1.4426950408889634f;
+    const SplitChoice sc = choose_split(B, Nq, Nkv, H, device_cus(), workspace_bytes);
+    AttnParams P;
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.out = (bf16*)out;
+    P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.Nq = Nq; P.Nkv = Nkv; P.H = H;
+    P.nqb = (int)nqb; P.R = sc.R; P.S = sc.S; P.nfull = (int)(nqb - sc.R);
+    const int64_t total_direct = (int64_t)B * H * P.nfull, pieces = (int64_t)B * H * sc.R * sc.S;
+    FG_CHECK_ARG(total_direct + pieces < (1ll << 30), "fg_attn_fwd_bf16: grid too large");
+    P.total_direct = (int)total_direct;
+    P.scale_log2e = scale * 1.4426950408889634f;
+    P.o_part = (float*)workspace;
+    P.ml_part = (float*)workspace + pieces * kBM * kD;
 #if FG_ATTN_VARIANT == 4
-    hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const bf16*)q, ldq,
-                       (const bf16*)k, ldk, (const bf16*)v, ldv, (bf16*)out, Nq, Nkv, H, (int)nqb, (int)total, scale_log2e);
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3((unsigned)(total_direct + pieces)), dim3(256), 0, (hipStream_t)stream, P);
 #else
-    hipLaunchKernelGGL((attn_fwd_kernel<8, 1>), dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, (const bf16*)q, ldq,
-                       (const bf16*)k, ldk, (const bf16*)v, ldv, (bf16*)out, Nq, Nkv, H, (int)nqb, (int)total, scale_log2e);
+    hipLaunchKernelGGL((attn_fwd_kernel<8, 1>), dim3((unsigned)(total_direct + pieces)), dim3(512), 0, (hipStream_t)stream, P);
 #endif
-    return fg_launch_status("fg_attn_fwd_bf16");
+    if (int e = fg_launch_status("fg_attn_fwd_bf16")) return e;
+    if (pieces > 0) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((int64_t)B * H * sc.R)), dim3(256), 0, (hipStream_t)stream, P);
+        return fg_launch_status("fg_attn_fwd_bf16 (combine)");
+    }
+    return FG_OK;
 }

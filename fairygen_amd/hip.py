@@ -25,7 +25,7 @@ _SIGNATURES = {
     "fg_residual_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
     "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
-    "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp],
+    "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "fg_conv_pack_weight_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -38,7 +38,7 @@ _SIGNATURES = {
     "fg_vae_tile_finalize_bf16": [_vp, _vp, _i32, _i32, _i32, _vp],
     "fg_video_to_uint8": [_vp, _vp, _i32, _i32, _i32, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice"])
 
 
 class HipLibraryError(RuntimeError):
@@ -63,6 +63,10 @@ def load():
     lib.fg_last_error.restype = ctypes.c_char_p
     lib.fg_conv_packed_bytes.restype = ctypes.c_int64
     lib.fg_conv_packed_bytes.argtypes = [_i32] * 5
+    lib.fg_attn_workspace_bytes.restype = ctypes.c_int64
+    lib.fg_attn_workspace_bytes.argtypes = [_i32, _i64, _i64, _i32]
+    lib.fg_attn_split_choice.restype = ctypes.c_int
+    lib.fg_attn_split_choice.argtypes = [_i32, _i64, _i64, _i32, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
@@ -232,6 +236,9 @@ def _ld_rows(t, name):
     return ld
 
 
+_attn_workspace = {}      # device -> scratch tensor for the split-KV partials (grown on demand, reused)
+
+
 def attention(q, k, v, num_heads, out=None):
     """softmax(q k^T / sqrt(d)) v, "b s (n d)" in and out (AttentionModule semantics)."""
     ldq, ldk, ldv = _ld_rows(q, "q"), _ld_rows(k, "k"), _ld_rows(v, "v")
@@ -239,8 +246,12 @@ def attention(q, k, v, num_heads, out=None):
     nkv = k.shape[1]
     d = hd // num_heads
     out = torch.empty((b, nq, hd), dtype=q.dtype, device=q.device) if out is None else out
+    need = load().fg_attn_workspace_bytes(b, nq, nkv, num_heads)
+    ws = _attn_workspace.get(q.device)
+    if need > 0 and (ws is None or ws.numel() < need):
+        ws = _attn_workspace[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
     _call("fg_attn_fwd_bf16", _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), b, nq, nkv, num_heads, d,
-          float(d) ** -0.5, _stream(q))
+          float(d) ** -0.5, _ptr(ws) if need > 0 else None, need, _stream(q))
     return out
 
 

@@ -87,10 +87,18 @@ int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t strea
 /* Non-causal softmax attention, head_dim 128: flash_attention()/AttentionModule,
  * models/wan_video_dit.py:27-60,113-120 (SDPA semantics: softmax(q k^T * scale) v, fp32 accumulate).
  * q:(B,Nq,H*128) k,v:(B,Nkv,H*128) with leading dimensions ldq/ldk/ldv (elements between token rows) and
- * batch strides Nq*ldq etc.; out (B,Nq,H*128) contiguous.  bf16 MFMA, fp32 online softmax. */
+ * batch strides Nq*ldq etc.; out (B,Nq,H*128) contiguous.  bf16 MFMA, fp32 online softmax.
+ * workspace (optional, may be NULL/0): fg_attn_workspace_bytes(B,Nq,Nkv,H) bytes of scratch let the launcher cut
+ * the tail q-blocks (or, for short query ranges such as a 1/8 token shard, every q-block) into KV ranges that are
+ * merged by a second small kernel, so that the workgroup count fills the 256 CUs evenly; results are the same up
+ * to fp32 summation order.  K/V of one batch element must span < 4 GiB. */
+int64_t fg_attn_workspace_bytes(int B, int64_t Nq, int64_t Nkv, int H);
+/* Diagnostic: the decomposition the launcher picks for this shape and workspace size: the last R q-blocks of every
+ * (batch, head) are cut into S KV ranges (R == 0: no split). */
+int fg_attn_split_choice(int B, int64_t Nq, int64_t Nkv, int H, int64_t workspace_bytes, int* R, int* S);
 int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                      void* out, int B, int64_t Nq, int64_t Nkv, int H, int D, float scale,
-                     fg_stream_t stream);
+                     void* workspace, int64_t workspace_bytes, fg_stream_t stream);
 
 /* One scheduler step on the latent: pred = nega + cfg*(posi - nega) (pipelines/wan_video.py:302);
  * out = latents + pred*dsigma (FlowMatchScheduler.step, diffusion/flow_match.py:144-154), each op rounded

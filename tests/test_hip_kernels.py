@@ -147,6 +147,18 @@ def test_attention_shapes(hip, nq, nkv, heads):
     _attn_case(hip, nq, nkv, heads, 20)
 
 
+@pytest.mark.parametrize("nq,nkv,heads,mode", [(300, 1000, 24, "all"), (13618, 2000, 24, "tail"), (3410 // 4, 2700, 24, "all")])
+def test_attention_split_kv(hip, nq, nkv, heads, mode):
+    """Shapes for which the launcher cuts q-blocks into KV ranges merged by the combine kernel (work balancing)."""
+    import ctypes
+    R, S = ctypes.c_int(), ctypes.c_int()
+    lib = hip.load()
+    assert lib.fg_attn_split_choice(1, nq, nkv, heads, lib.fg_attn_workspace_bytes(1, nq, nkv, heads), ctypes.byref(R), ctypes.byref(S)) == 0
+    nqb = (nq + 255) // 256
+    assert S.value > 1 and R.value == (nqb if mode == "all" else 1), (R.value, S.value)
+    _attn_case(hip, nq, nkv, heads, 25)
+
+
 def test_attention_peaked_softmax(hip):
     # large-magnitude queries: near one-hot softmax rows exercise the running-max rescale path
     _attn_case(hip, 200, 333, 2, 30, scale_q=8.0)

@@ -38,7 +38,7 @@ def test_no_cpu_fallback():
 
 def test_argument_validation_through_the_c_abi():
     lib = hip.load()
-    rc = lib.fg_attn_fwd_bf16(None, 0, None, 0, None, 0, None, 1, 1, 1, 1, 128, 1.0, None)
+    rc = lib.fg_attn_fwd_bf16(None, 0, None, 0, None, 0, None, 1, 1, 1, 1, 128, 1.0, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.fg_last_error()
     rc = lib.fg_conv3d_cl_bf16(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, ctypes.c_void_p(16),
                                1, 4, 4, 8, 8, 2, 3, 0, 0, None)
