@@ -157,12 +157,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        backend = os.environ.get("FAIRYGEN_BENCH_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fairygen_amd import hip
@@ -215,7 +219,7 @@ def main():
         t_clip = time.perf_counter() - t0
         timer.uninstall()
     if world > 1:
-        tt = torch.tensor([t_clip], device=device, dtype=torch.float64)
+        tt = torch.tensor([t_clip], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_clip = tt.item()
 

@@ -41,7 +41,13 @@ class TokenShard:
             buf = torch.zeros((size, c), dtype=local.dtype, device=local.device)
             buf[: local.shape[0]].copy_(local)
         full = torch.empty((self.world_size * size, c), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(full, buf, group=self.group)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # backend without device-tensor collectives (single-GPU rehearsal): stage through the host
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, buf.cpu(), group=self.group)
+            full.copy_(host)
+        else:
+            dist.all_gather_into_tensor(full, buf, group=self.group)
         return full
 
     def all_gather_kv(self, k, v, n=None):
@@ -66,5 +72,11 @@ class TokenShard:
     def broadcast(self, tensor, src):
         """In-place broadcast from group rank `src` (VAE tiles decoded round-robin over ranks)."""
         if self.world_size > 1:
-            dist.broadcast(tensor, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+            gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+            if tensor.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = tensor.cpu()
+                dist.broadcast(host, src=gsrc, group=self.group)
+                tensor.copy_(host)
+            else:
+                dist.broadcast(tensor, src=gsrc, group=self.group)
         return tensor
