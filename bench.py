@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=4096)
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
+    ap.add_argument("--cfg-streams", type=int, default=-1, help="-1 auto (on when sharded), 0 off, 1 on: CFG branches on two streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +175,8 @@ def main():
     pipe, cfg = build_pipeline(args, device)
     if world > 1:
         pipe.enable_sequence_parallel()
+    if args.cfg_streams >= 0:
+        pipe.cfg_streams = bool(args.cfg_streams)
     H, W, F_ = args.height, args.width, args.frames
     lat_shape = (1, 48, (F_ - 1) // 4 + 1, H // 16, W // 16)
     n_tokens = lat_shape[2] * (lat_shape[3] // 2) * (lat_shape[4] // 2)

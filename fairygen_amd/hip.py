@@ -236,7 +236,7 @@ def _ld_rows(t, name):
     return ld
 
 
-_attn_workspace = {}      # device -> scratch tensor for the split-KV partials (grown on demand, reused)
+_attn_workspace = {}      # (device, stream) -> scratch tensor for the split-KV partials (grown on demand, reused)
 
 
 def attention(q, k, v, num_heads, out=None):
@@ -247,9 +247,10 @@ def attention(q, k, v, num_heads, out=None):
     d = hd // num_heads
     out = torch.empty((b, nq, hd), dtype=q.dtype, device=q.device) if out is None else out
     need = load().fg_attn_workspace_bytes(b, nq, nkv, num_heads)
-    ws = _attn_workspace.get(q.device)
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)      # concurrent streams must not share scratch
+    ws = _attn_workspace.get(key)
     if need > 0 and (ws is None or ws.numel() < need):
-        ws = _attn_workspace[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
+        ws = _attn_workspace[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
     _call("fg_attn_fwd_bf16", _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), b, nq, nkv, num_heads, d,
           float(d) ** -0.5, _ptr(ws) if need > 0 else None, need, _stream(q))
     return out

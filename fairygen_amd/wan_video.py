@@ -165,6 +165,8 @@ class WanVideoPipeline(torch.nn.Module):
         self.post_units = []
         self.model_fn = model_fn_wan_video
         self.sequence_shard = None          # set by enable_sequence_parallel()
+        self.cfg_streams = None             # None: two-stream CFG branches iff tokens are sharded; True / False to force
+        self._cfg_side_streams = None
         self.use_unified_sequence_parallel = False
 
     # ----------------------------------------------------------------------------- construction
@@ -308,20 +310,42 @@ class WanVideoPipeline(torch.nn.Module):
 
     def denoise(self, inputs_shared, inputs_posi, inputs_nega, cfg_scale, progress_bar_cmd=tqdm):
         """The hot loop: per step forward(+), forward(-), then CFG combine + Euler step fused in one HIP kernel,
-        then the first latent frame re-pinned (TI2V)."""
+        then the first latent frame re-pinned (TI2V).
+
+        With `cfg_streams` (default: on when the tokens are sharded over several GPUs) the two CFG branches — which
+        are independent until the combine — are issued on two HIP streams: one branch's K/V all-gather over xGMI then
+        runs under the other branch's GEMMs / attention instead of stalling the device.  Collectives are still issued
+        in the same program order on every rank."""
         models = {name: getattr(self, name) for name in self.in_iteration_models}
         shared = {k: v for k, v in inputs_shared.items() if k in ("latents", "fuse_vae_embedding_in_latents")}
         shared["sequence_shard"] = self.sequence_shard
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
+        sharded = self.sequence_shard is not None and self.sequence_shard.world_size > 1
+        two_streams = (self.cfg_streams if self.cfg_streams is not None else sharded) and cfg_scale != 1.0 and latents.is_cuda
+        if two_streams and self._cfg_side_streams is None:
+            self._cfg_side_streams = (torch.cuda.Stream(latents.device), torch.cuda.Stream(latents.device))
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
-            posi = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_posi), timestep=ts)
-            nega = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_nega), timestep=ts) if cfg_scale != 1.0 else None
+            if two_streams:
+                main = torch.cuda.current_stream(latents.device)
+                outs = []
+                for side, ctx in zip(self._cfg_side_streams, (inputs_posi, inputs_nega)):
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        o = self.model_fn(**models, **shared, **inputs_posi_ctx(ctx), timestep=ts).contiguous()
+                    o.record_stream(main)
+                    outs.append(o)
+                for side in self._cfg_side_streams:
+                    main.wait_stream(side)
+                posi, nega = outs
+            else:
+                posi = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_posi), timestep=ts).contiguous()
+                nega = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_nega), timestep=ts).contiguous() \
+                    if cfg_scale != 1.0 else None
             sigma, sigma_next = self.scheduler.step_scalars(self.scheduler.timesteps[progress_id])
-            latents = hip.cfg_euler(latents, posi.contiguous(), None if nega is None else nega.contiguous(),
-                                    cfg_scale, float(sigma_next - sigma))
+            latents = hip.cfg_euler(latents, posi, nega, cfg_scale, float(sigma_next - sigma))
             if first is not None:
                 latents[:, :, 0:1] = first
         return latents
