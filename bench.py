@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=4096)
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
-    ap.add_argument("--cfg-streams", type=int, default=-1, help="-1 auto (on when sharded), 0 off, 1 on: CFG branches on two streams")
+    ap.add_argument("--cfg-streams", type=int, default=-1, help="1: CFG branches on two HIP streams (experimental; default off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

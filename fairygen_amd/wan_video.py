@@ -165,7 +165,7 @@ class WanVideoPipeline(torch.nn.Module):
         self.post_units = []
         self.model_fn = model_fn_wan_video
         self.sequence_shard = None          # set by enable_sequence_parallel()
-        self.cfg_streams = None             # None: two-stream CFG branches iff tokens are sharded; True / False to force
+        self.cfg_streams = False            # True: issue the two CFG branches on two HIP streams (experimental)
         self._cfg_side_streams = None
         self.use_unified_sequence_parallel = False
 
@@ -312,7 +312,7 @@ class WanVideoPipeline(torch.nn.Module):
         """The hot loop: per step forward(+), forward(-), then CFG combine + Euler step fused in one HIP kernel,
         then the first latent frame re-pinned (TI2V).
 
-        With `cfg_streams` (default: on when the tokens are sharded over several GPUs) the two CFG branches — which
+        With `cfg_streams=True` (opt-in, off by default) the two CFG branches — which
         are independent until the combine — are issued on two HIP streams: one branch's K/V all-gather over xGMI then
         runs under the other branch's GEMMs / attention instead of stalling the device.  Collectives are still issued
         in the same program order on every rank."""
@@ -321,8 +321,7 @@ class WanVideoPipeline(torch.nn.Module):
         shared["sequence_shard"] = self.sequence_shard
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
-        sharded = self.sequence_shard is not None and self.sequence_shard.world_size > 1
-        two_streams = (self.cfg_streams if self.cfg_streams is not None else sharded) and cfg_scale != 1.0 and latents.is_cuda
+        two_streams = bool(self.cfg_streams) and cfg_scale != 1.0 and latents.is_cuda
         if two_streams and self._cfg_side_streams is None:
             self._cfg_side_streams = (torch.cuda.Stream(latents.device), torch.cuda.Stream(latents.device))
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
