@@ -25,6 +25,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+# HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r01_attn_pmc_hbm.json:
+# separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, gfx950 x2 correction on FETCH_SIZE), keyed by (Nq, Nkv, H).
+# PMC collection cannot run inside the timed bench; other shapes report null.
+PMC_HBM_BYTES_PER_LAUNCH = {(27280, 27280, 24): 2.094e9}
 
 
 def seeded(shape, seed, dtype=torch.bfloat16):
@@ -87,15 +91,16 @@ class KernelTimer:
         hip.attention = self._orig
 
     def self_attention_stats(self):
-        durs, flops = [], 0.0
+        durs, flops, shape = [], 0.0, None
         for nq, nkv, h, s, e in self.records:
             if nkv > 1024:         # self-attention launches (cross-attention has Nkv = 512)
                 durs.append(s.elapsed_time(e) * 1e-3)
-                flops = 4.0 * nq * nkv * h * 128
+                flops, shape = 4.0 * nq * nkv * h * 128, (nq, nkv, h)
         if not durs:
             return None
         avg = sum(durs) / len(durs)
-        return {"launches": len(durs), "avg_s": avg, "flops_per_launch": flops, "tflops": flops / avg / 1e12}
+        return {"launches": len(durs), "avg_s": avg, "flops_per_launch": flops, "tflops": flops / avg / 1e12,
+                "traffic": PMC_HBM_BYTES_PER_LAUNCH.get(shape)}
 
 
 def cpu_baseline(args, n_tokens, frames, steps):
@@ -232,7 +237,7 @@ def main():
         if st:
             roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel (fg_attn_fwd_bf16, self-attention launches)",
                         "achieved": round(st["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(st["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "frac": round(st["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": st["traffic"],
                         "launches": st["launches"], "avg_launch_ms": round(st["avg_s"] * 1e3, 3),
                         "flops_per_launch": st["flops_per_launch"]}
         line = {
