@@ -35,7 +35,6 @@ namespace {
 
 constexpr int kD = 128;      // head dim
 constexpr int kBN = 64;      // keys per tile
-constexpr int kBM = 256;     // query rows per workgroup
 constexpr int kTileBytes = kBN * kD * 2;  // 16 KiB
 constexpr float kDeferLog2 = 6.0f;        // rescale O only if a row max grows by > 2^6 (P <= 64)
 
@@ -72,6 +71,15 @@ __device__ __forceinline__ float pair_sum(float x) {
 // partial O / running max / row sum go to the workspace and are merged by attn_combine_kernel.  Direct workgroups get
 // the low block ids (dispatched first), the small pieces fill the tail: wave quantisation (2568 workgroups on 256 CUs
 // = 10.03 rounds at N = 27 280; 336 = 1.31 rounds for a 1/8 token shard) costs a fraction of a piece instead of a round.
+#ifndef FG_ATTN_VARIANT
+#define FG_ATTN_VARIANT 8      // 8: <8 waves, 1 q-block> (256 rows / WG); 4: <4 waves, 1 q-block> (128 rows, 2 WGs per CU)
+#endif
+#if FG_ATTN_VARIANT == 4
+constexpr int kBM = 128;
+#else
+constexpr int kBM = 256;       // query rows per workgroup
+#endif
+
 struct AttnParams {
     const bf16* q; const bf16* k; const bf16* v; bf16* out;
     int64_t ldq, ldk, ldv, Nq, Nkv;
@@ -82,13 +90,13 @@ struct AttnParams {
 };
 
 template <int WAVES, int QB>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kernel(const AttnParams P) {
+__global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(const AttnParams P) {
     const bf16* __restrict__ q = P.q; const bf16* __restrict__ k = P.k; const bf16* __restrict__ v = P.v;
     bf16* __restrict__ out = P.out;
     const int64_t ldq = P.ldq, ldk = P.ldk, ldv = P.ldv, Nq = P.Nq, Nkv = P.Nkv;
     const int H = P.H;
     const float scale_log2e = P.scale_log2e;
-    static_assert(WAVES * QB * 32 == kBM, "workgroup covers 256 query rows");
+    static_assert(WAVES * QB * 32 == kBM, "workgroup rows");
     constexpr int THREADS = WAVES * 64;
     constexpr int NST = (kBN * 16) / THREADS;      // 16-byte chunks per thread per tile (2 or 4)
     constexpr int ST_ROWS = THREADS / 16;          // rows covered per staging pass
@@ -370,33 +378,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void attn_fwd_kerne
 
 // Merge the S partials of every split q-block: out = sum_s w_s O_s / sum_s w_s l_s, w_s = 2^((m_s - max m) * scale*log2e).
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams P) {
-    const int blk = blockIdx.x;                // (bh, rq)
+    // one workgroup per 8 rows of a split q-block: 32 lanes x float4 cover d = 128
+    const int rows_per_blk = 8, groups = kBM / rows_per_blk;
+    const int blk = blockIdx.x / groups, rowgrp = blockIdx.x % groups;      // blk = (bh, rq)
     const int rq = blk % P.R, bh = blk / P.R;
     const int b = bh / P.H, h = bh % P.H;
     const int qb = P.nfull + rq;
-    const int lane32 = threadIdx.x & 31, rsub = threadIdx.x >> 5;      // 8 rows per pass, one float4 of d per lane
+    const int lane32 = threadIdx.x & 31, row = rowgrp * rows_per_blk + (threadIdx.x >> 5);
     const int64_t piece0 = ((int64_t)bh * P.R + rq) * P.S;
-    for (int row = rsub; row < kBM; row += 8) {
-        const int64_t qrow = (int64_t)qb * kBM + row;
-        if (qrow >= P.Nq) break;
-        float mmax = -INFINITY;
-        for (int sp = 0; sp < P.S; ++sp) mmax = fmaxf(mmax, P.ml_part[((piece0 + sp) * kBM + row) * 2]);
-        float denom = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < P.S; ++sp) {
-            const float* ml = P.ml_part + ((piece0 + sp) * kBM + row) * 2;
-            const float w = fast_exp2((ml[0] - mmax) * P.scale_log2e);
-            denom += w * ml[1];
-            const f32x4 ov = *reinterpret_cast<const f32x4*>(P.o_part + ((piece0 + sp) * kBM + row) * kD + lane32 * 4);
+    const int64_t qrow = (int64_t)qb * kBM + row;
+    if (qrow >= P.Nq) return;
+    float mmax = -INFINITY;
+    for (int sp = 0; sp < P.S; ++sp) mmax = fmaxf(mmax, P.ml_part[((piece0 + sp) * kBM + row) * 2]);
+    float denom = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < P.S; ++sp) {
+        const float* ml = P.ml_part + ((piece0 + sp) * kBM + row) * 2;
+        const float w = fast_exp2((ml[0] - mmax) * P.scale_log2e);
+        denom += w * ml[1];
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(P.o_part + ((piece0 + sp) * kBM + row) * kD + lane32 * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += w * ov[j];
-        }
-        const float inv = 1.0f / denom;
-        bf16x4 w4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w4[j] = (bf16)(acc[j] * inv);
-        *reinterpret_cast<bf16x4*>(P.out + ((int64_t)b * P.Nq + qrow) * ((int64_t)P.H * kD) + (int64_t)h * kD + lane32 * 4) = w4;
+        for (int j = 0; j < 4; ++j) acc[j] += w * ov[j];
     }
+    const float inv = 1.0f / denom;
+    bf16x4 w4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (bf16)(acc[j] * inv);
+    *reinterpret_cast<bf16x4*>(P.out + ((int64_t)b * P.Nq + qrow) * ((int64_t)P.H * kD) + (int64_t)h * kD + lane32 * 4) = w4;
 }
 
 // ---- host-side choice of (R, S): greedy list-scheduling estimate of the makespan on `cus` compute units
@@ -469,14 +477,10 @@ static int device_cus() {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached_cus = n;
         cached_dev = dev;
     }
-    return cached_cus;
+    return cached_cus * (256 / kBM);      // concurrent workgroup slots (two 128-row workgroups share a CU)
 }
 
 }  // namespace
-
-#ifndef FG_ATTN_VARIANT
-#define FG_ATTN_VARIANT 8      // 8: <8 waves, 1 q-block>; 4: <4 waves, 2 q-blocks>
-#endif
 
 extern "C" int64_t fg_attn_workspace_bytes(int B, int64_t Nq, int64_t Nkv, int H) {
     if (B <= 0 || Nq <= 0 || Nkv <= 0 || H <= 0) return 0;
@@ -519,13 +523,13 @@ extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64
     P.o_part = (float*)workspace;
     P.ml_part = (float*)workspace + pieces * kBM * kD;
 #if FG_ATTN_VARIANT == 4
-    hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3((unsigned)(total_direct + pieces)), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 1>), dim3((unsigned)(total_direct + pieces)), dim3(256), 0, (hipStream_t)stream, P);
 #else
     hipLaunchKernelGGL((attn_fwd_kernel<8, 1>), dim3((unsigned)(total_direct + pieces)), dim3(512), 0, (hipStream_t)stream, P);
 #endif
     if (int e = fg_launch_status("fg_attn_fwd_bf16")) return e;
     if (pieces > 0) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((int64_t)B * H * sc.R)), dim3(256), 0, (hipStream_t)stream, P);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((int64_t)B * H * sc.R * (kBM / 8))), dim3(256), 0, (hipStream_t)stream, P);
         return fg_launch_status("fg_attn_fwd_bf16 (combine)");
     }
     return FG_OK;

@@ -63,6 +63,13 @@ class TokenShard:
         vf = self._gather_rows(v[0], size)[:n].unsqueeze(0)
         return kf, vf
 
+    def all_gather_kv_async(self, k, v, n):
+        """Start the K/V all-gather without blocking the compute stream; `.wait()` -> (k_full, v_full).
+
+        The collectives run on the process group's own stream, so whatever the caller enqueues between this call
+        and wait() — in the pipeline: the other CFG branch's GEMMs / attention — overlaps the xGMI transfer."""
+        return _PendingKV(self, k, v, n)
+
     def all_gather_tokens(self, x, n):
         """x (1, n_local, C) -> (1, N, C) (final head all-gather, wan_video.py:1379-1382)."""
         if self.world_size == 1:
@@ -80,3 +87,33 @@ class TokenShard:
             else:
                 dist.broadcast(tensor, src=gsrc, group=self.group)
         return tensor
+
+
+class _PendingKV:
+    def __init__(self, shard, k, v, n):
+        self.n, self.works = n, []
+        if shard.world_size == 1:
+            self.kf, self.vf = k[0], v[0]
+            return
+        size = shard.chunk(n)
+        staged = k.is_cuda and dist.get_backend(shard.group) == "gloo"
+        if staged:      # single-GPU rehearsal backend: synchronous, through the host
+            self.kf, self.vf = shard._gather_rows(k[0], size), shard._gather_rows(v[0], size)
+            return
+        bufs = []
+        for t in (k[0], v[0]):
+            if t.shape[0] == size and t.is_contiguous():
+                buf = t
+            else:
+                buf = torch.zeros((size, t.shape[-1]), dtype=t.dtype, device=t.device)
+                buf[: t.shape[0]].copy_(t)
+            full = torch.empty((shard.world_size * size, t.shape[-1]), dtype=t.dtype, device=t.device)
+            self.works.append(dist.all_gather_into_tensor(full, buf, group=shard.group, async_op=True))
+            bufs.append((full, buf))
+        self._keep = bufs      # keep the send buffers alive until wait()
+        self.kf, self.vf = bufs[0][0], bufs[1][0]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return self.kf[: self.n].unsqueeze(0), self.vf[: self.n].unsqueeze(0)

@@ -322,6 +322,11 @@ class WanVideoPipeline(torch.nn.Module):
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
         two_streams = bool(self.cfg_streams) and cfg_scale != 1.0 and latents.is_cuda
+        # Token-sharded runs: the two CFG branches are independent until the combine, so they are advanced in lockstep
+        # on ONE stream, each yielding right after it has started its K/V all-gather: branch B's GEMMs run while A's
+        # K/V cross xGMI, A's attention / FFN while B's do.  Collectives keep one program order on every rank.
+        sharded = self.sequence_shard is not None and self.sequence_shard.world_size > 1
+        interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not two_streams
         if two_streams and self._cfg_side_streams is None:
             self._cfg_side_streams = (torch.cuda.Stream(latents.device), torch.cuda.Stream(latents.device))
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
@@ -339,6 +344,10 @@ class WanVideoPipeline(torch.nn.Module):
                 for side in self._cfg_side_streams:
                     main.wait_stream(side)
                 posi, nega = outs
+            elif interleave:
+                gens = [model_fn_wan_video_steps(**models, **shared, **inputs_posi_ctx(c), timestep=ts)
+                        for c in (inputs_posi, inputs_nega)]
+                posi, nega = (o.contiguous() for o in run_interleaved(gens))
             else:
                 posi = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_posi), timestep=ts).contiguous()
                 nega = self.model_fn(**models, **shared, **inputs_posi_ctx(inputs_nega), timestep=ts).contiguous() \
@@ -357,7 +366,33 @@ def inputs_posi_ctx(d):
 # ------------------------------------------------------------------------------------- the DiT forward
 def model_fn_wan_video(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
                        sequence_shard=None, **kwargs):
-    """One DiT forward (TI2V-5B / T2V branches of pipelines/wan_video.py:1217-1388).
+    """One DiT forward (TI2V-5B / T2V branches of pipelines/wan_video.py:1217-1388); see model_fn_wan_video_steps."""
+    gen = model_fn_wan_video_steps(dit, latents=latents, timestep=timestep, context=context,
+                                   fuse_vae_embedding_in_latents=fuse_vae_embedding_in_latents,
+                                   sequence_shard=sequence_shard, **kwargs)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as done:
+            return done.value
+
+
+def run_interleaved(generators):
+    """Advance several independent step-generators round-robin until all are exhausted; returns their values."""
+    results, live = [None] * len(generators), list(range(len(generators)))
+    while live:
+        for i in list(live):
+            try:
+                next(generators[i])
+            except StopIteration as done:
+                results[i] = done.value
+                live.remove(i)
+    return results
+
+
+def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
+                             sequence_shard=None, **kwargs):
+    """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction).
 
     timestep: (1,) tensor already rounded to the pipeline dtype (host or device).  The per-token time embedding of
     the reference (:1219-1228) has only two distinct rows (t=0 for the first latent frame, t elsewhere): both rows
@@ -384,9 +419,9 @@ def model_fn_wan_video(dit, latents=None, timestep=None, context=None, fuse_vae_
     if sequence_shard is not None and sequence_shard.world_size > 1:
         lo, hi = sequence_shard.local_range(n)
         x_loc = x[:, lo:hi].contiguous()
-        out_loc = dit.forward_tokens(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
-                                     (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n)
+        out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
+                                                      (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n)
         out = sequence_shard.all_gather_tokens(out_loc, n)
     else:
-        out = dit.forward_tokens(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin))
+        out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin))
     return dit.unpatchify(out, (f, h, w))

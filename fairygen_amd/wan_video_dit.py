@@ -189,13 +189,25 @@ class WanModel(nn.Module):
 
     # ------------------------------------------------------------------ the 30-block token forward
     def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
-        """x (1,n,dim) local tokens; context (1,L,dim) embedded text; t_rows (R,dim) distinct time embeddings
+        """Run forward_tokens_steps to completion (single branch)."""
+        gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+
+    def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
+        """Generator form of the 30-block forward: yields right after each block's K/V all-gather has been STARTED
+        (token-sharded runs only), so a driver can interleave two independent forwards (the CFG branches) and let
+        one branch's compute hide the other's xGMI traffic.  Returns (StopIteration.value) the head output.
+
+        x (1,n,dim) local tokens; context (1,L,dim) embedded text; t_rows (R,dim) distinct time embeddings
         (R = 1 or 2), mod_rows_t (R,6,dim) their projections; tokens < first_rows use row 0.
         rope = (cos, sin) for the LOCAL tokens.  shard: optional fairygen_amd.sequence_parallel.TokenShard —
-        K/V are all-gathered over it before self-attention (shard_total = N, all ranks' tokens).  Returns head output (1,n,out*patch)."""
+        K/V are all-gathered over it before self-attention (shard_total = N, all ranks' tokens)."""
         c, nh, eps = self.dim, self.num_heads, self.eps
         cos, sin = rope
-        n = x.shape[1]
         x = x.contiguous()
         blocks = list(self.blocks)
         mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
@@ -206,11 +218,15 @@ class WanModel(nn.Module):
             sa, ca = blk.self_attn, blk.cross_attn
             # --- self attention (reference :139-146)
             qkv = F.linear(h, wqkv, bqkv)
-            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
             k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
             v = qkv[..., 2 * c:]
-            if shard is not None:
-                k, v = shard.all_gather_kv(k, v, shard_total)
+            pending = None
+            if shard is not None and shard.world_size > 1:
+                pending = shard.all_gather_kv_async(k, v, shard_total)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+            if pending is not None:
+                yield i
+                k, v = pending.wait()
             y = F.linear(sa.attn(q, k, v), sa.o.weight, sa.o.bias)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
             x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)

@@ -28,6 +28,10 @@ def _worker(rank, world, port, n_tokens, result_dir):
         assert torch.equal(kf, k) and torch.equal(vf, v)
         kf2, _ = shard.all_gather_kv(k[:, lo:hi].contiguous(), v[:, lo:hi].contiguous())   # N inferred by all-reduce
         assert torch.equal(kf2, k)
+        pend_a = shard.all_gather_kv_async(k[:, lo:hi], v[:, lo:hi], n_tokens)             # two gathers in flight, as the
+        pend_b = shard.all_gather_kv_async(q[:, lo:hi], k[:, lo:hi], n_tokens)             # interleaved CFG branches do
+        (ka, va), (kb, vb) = pend_a.wait(), pend_b.wait()
+        assert torch.equal(ka, k) and torch.equal(va, v) and torch.equal(kb, q) and torch.equal(vb, k)
         out_local = wan_dit.attention(q[:, lo:hi], kf, vf, heads)
         full = shard.all_gather_tokens(out_local, n_tokens)
         want = wan_dit.attention(q, k, v, heads)
@@ -83,6 +87,24 @@ def _gpu_worker(rank, world, port, result_dir):
         torch.cuda.synchronize()
         err = (full.float() - shard.float()).abs().max().item()
         assert err <= 2.0 ** -6 * full.float().abs().max().item(), f"sharded forward differs: {err}"
+        # the denoise loop: sharded runs interleave the two CFG branches around their K/V gathers
+        from fairygen_amd.wan_video import WanVideoPipeline
+        ctx_n, z0 = seeded((1, 24, 128), 7).cuda(), seeded((1, 48, 1, 10, 14), 8).cuda()
+        outs = []
+        for sharded in (False, True):
+            pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+            pipe.dit = m
+            if sharded:
+                pipe.enable_sequence_parallel()
+            pipe.scheduler.set_timesteps(3, denoising_strength=1.0, shift=5.0)
+            lat0 = lat.clone()
+            lat0[:, :, 0:1] = z0
+            shared = {"latents": lat0, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0}
+            with torch.no_grad():
+                outs.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
+        torch.cuda.synchronize()
+        err = (outs[0].float() - outs[1].float()).abs().max().item()
+        assert err <= 0.05 * outs[0].float().abs().max().item(), f"sharded denoise loop differs: {err}"
         open(os.path.join(result_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
