@@ -31,7 +31,7 @@ struct ConvParams {
     const bf16* bias;
     const bf16* residual;
     bf16* out;
-    int T, H, W, Hin, Win, Cin, Cout, kt, ks, cin_pad, cout_pad, upsample, interleave;
+    int T, H, W, Hin, Win, Cin, Cout, kt, ks, cin_pad, cout_pad, upsample, downsample, interleave;
     int64_t M;              // T*H*W output pixels
     uint32_t x_bytes, w_bytes;
 };
@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
         w_off[i] = (uint32_t)(((c0 + st_row + 32 * i) * p.cin_pad + st_chunk * 8) * 2);
         st_lds[i] = lds_off(st_row + 32 * i, st_chunk);
     }
-    const int pad = p.ks >> 1;
+    // stride-2 "downsample" mode = ZeroPad2d((0,1,0,1)) + Conv2d(stride 2): input row 2y + dy, no leading pad
+    const int pad = p.downsample ? 0 : (p.ks >> 1);
+    const int sstride = p.downsample ? 2 : 1;
     const int ksteps_per_tap = p.cin_pad / kBK;
     const int ntaps = p.kt * p.ks * p.ks;
     const int nsteps = ntaps * ksteps_per_tap;
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
     auto tap_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int yy = py[i] + ld_dy - pad, xx = px[i] + ld_dx - pad;
-            const bool ok = pv[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            int yy = py[i] * sstride + ld_dy - pad, xx = px[i] * sstride + ld_dx - pad;
+            const bool ok = pv[i] && yy >= 0 && yy < p.H * sstride && xx >= 0 && xx < p.W * sstride;
             if (p.upsample) { yy >>= 1; xx >>= 1; }
             const uint32_t off = (uint32_t)((((pt[i] + ld_dt) * p.Hin + yy) * p.Win + xx) * p.Cin + st_chunk * 8) * 2u;
             x_off[i] = ok ? off : kOOB;
@@ -247,7 +249,10 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
 }
 
 int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, const void* residual, void* out, int T, int H,
-                      int W, int Cin, int Cout, int kt, int ks, int upsample2x, int time_interleave, fg_stream_t stream) {
+                      int W, int Cin, int Cout, int kt, int ks, int resample, int time_interleave, fg_stream_t stream) {
+    const int upsample2x = resample == 1, downsample2x = resample == 2;
+    FG_CHECK_ARG(resample >= 0 && resample <= 2, "fg_conv3d_cl_bf16: resample must be 0 (none), 1 (nearest 2x up) or 2 (stride-2 down)");
+    FG_CHECK_ARG(!downsample2x || (kt == 1 && ks == 3), "fg_conv3d_cl_bf16: stride-2 mode is the 3x3 Conv2d of Resample38 downsample");
     FG_CHECK_ARG(x && w_packed && bias && out, "fg_conv3d_cl_bf16: null pointer");
     FG_CHECK_ARG(T > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "fg_conv3d_cl_bf16: sizes must be positive");
     FG_CHECK_ARG((kt == 1 || kt == 3) && (ks == 1 || ks == 3), "fg_conv3d_cl_bf16: kt and ks must be 1 or 3");
@@ -260,10 +265,11 @@ int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, con
     ConvParams p;
     p.x = (const bf16*)x; p.wp = (const bf16*)w_packed; p.bias = (const bf16*)bias;
     p.residual = (const bf16*)residual; p.out = (bf16*)out;
-    p.T = T; p.H = H; p.W = W; p.Hin = upsample2x ? H / 2 : H; p.Win = upsample2x ? W / 2 : W;
+    p.T = T; p.H = H; p.W = W;
+    p.Hin = upsample2x ? H / 2 : (downsample2x ? 2 * H : H); p.Win = upsample2x ? W / 2 : (downsample2x ? 2 * W : W);
     p.Cin = Cin; p.Cout = Cout; p.kt = kt; p.ks = ks;
     p.cin_pad = roundup(Cin, kBK); p.cout_pad = roundup(Cout, kBMc);
-    p.upsample = upsample2x ? 1 : 0; p.interleave = time_interleave ? 1 : 0;
+    p.upsample = upsample2x ? 1 : 0; p.downsample = downsample2x ? 1 : 0; p.interleave = time_interleave ? 1 : 0;
     p.M = (int64_t)T * H * W;
     const int64_t x_bytes = (int64_t)(T + kt - 1) * p.Hin * p.Win * Cin * 2;
     const int64_t w_bytes = fg_conv_packed_bytes(Cout, Cin, kt, ks, ks);

@@ -138,8 +138,8 @@ __device__ __forceinline__ float ramp(int i, int len, int border, bool lo_bound,
 }
 
 __global__ __launch_bounds__(256) void tile_accumulate_kernel(const bf16* __restrict__ tile, bf16* __restrict__ values,
-                                                              bf16* __restrict__ weight, int F, int Hv, int Wv, int th, int tw,
-                                                              int y0, int x0, int bh, int bw, int bound) {
+                                                              bf16* __restrict__ weight, int C, int F, int Hv, int Wv, int th,
+                                                              int tw, int y0, int x0, int bh, int bw, int bound) {
     const int64_t total = (int64_t)F * th * tw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int xx = (int)(i % tw);
@@ -150,8 +150,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const bf16* __rest
         const float mw = ramp(xx, tw, bw, bound & 4, bound & 8);
         const float m = rbf(fminf(mh, mw));
         const int64_t vo = ((int64_t)f * Hv + y0 + yy) * Wv + x0 + xx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < C; ++c) {
             const int64_t vi = (int64_t)c * F * Hv * Wv + vo;
             const float t = (float)tile[((int64_t)c * F + f) * th * tw + (int64_t)yy * tw + xx];
             values[vi] = (bf16)((float)values[vi] + rbf(t * m));
@@ -161,11 +160,64 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const bf16* __rest
 }
 
 __global__ __launch_bounds__(256) void tile_finalize_kernel(bf16* __restrict__ values, const bf16* __restrict__ weight,
-                                                            int64_t fhw) {
-    const int64_t total = 3 * fhw;
+                                                            int C, int64_t fhw, int do_clamp) {
+    const int64_t total = C * fhw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = rbf((float)values[i] / (float)weight[i % fhw]);
-        values[i] = (bf16)fminf(fmaxf(v, -1.f), 1.f);
+        values[i] = (bf16)(do_clamp ? fminf(fmaxf(v, -1.f), 1.f) : v);
+    }
+}
+
+// (3,T,H,W) -> patchify(.,2) 'c f (h q) (w r) -> (c r q) f h w' (models/wan_video_vae.py:199-211), channels-last out
+// padded to 16 channels (12 real + 4 zeros) so the first conv reads whole 16-byte chunks
+__global__ __launch_bounds__(256) void patchify_kernel(const bf16* __restrict__ video, bf16* __restrict__ out, int T, int H,
+                                                       int W) {      // H, W: patched (half) resolution
+    const int64_t total = (int64_t)T * H * W * 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 15);
+        int64_t pix = i >> 4;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int t = (int)(pix / H);
+        const int c = ch >> 2, r = (ch >> 1) & 1, q = ch & 1;
+        out[i] = ch < 12 ? video[(((int64_t)c * T + t) * (2 * H) + 2 * y + q) * (2 * W) + 2 * x + r] : (bf16)0.f;
+    }
+}
+
+// out = main + AvgDown3D(x): models/wan_video_vae.py:363-395,474.  x (T,H,W,Cin); main/out (To,H/fs,W/fs,Cout), To = ceil(T/ft);
+// a missing leading frame (T not a multiple of ft) counts as zeros, exactly like the reference's front padding.
+__global__ __launch_bounds__(256) void avgdown3d_add_kernel(const bf16* __restrict__ x, const bf16* __restrict__ main_path,
+                                                            bf16* __restrict__ out, int T, int H, int W, int Cin, int Cout,
+                                                            int ft, int fs) {
+    const int To = (T + ft - 1) / ft, Ho = H / fs, Wo = W / fs, pad_t = To * ft - T;
+    const int factor = ft * fs * fs, group = Cin * factor / Cout;
+    const int64_t total = (int64_t)To * Ho * Wo * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % Cout);
+        int64_t pix = i / Cout;
+        const int xo = (int)(pix % Wo); pix /= Wo;
+        const int yo = (int)(pix % Ho);
+        const int to = (int)(pix / Ho);
+        float acc = 0.f;
+        for (int gi = 0; gi < group; ++gi) {
+            const int cc = oc * group + gi;                 // index into (c, a, b, d) = C x ft x fs x fs
+            const int d = cc % fs, b = (cc / fs) % fs, a = (cc / (fs * fs)) % ft, c = cc / factor;
+            const int t = to * ft + a - pad_t;
+            if (t >= 0) acc += (float)x[(((int64_t)t * H + yo * fs + b) * W + xo * fs + d) * Cin + c];
+        }
+        out[i] = (bf16)((float)main_path[i] + rbf(acc / (float)group));
+    }
+}
+
+// encoder tail: x (T,h,w,2z) channels-last -> mu = first z channels, (mu - mean) * inv_std, out (z,T,h,w)
+__global__ __launch_bounds__(256) void latent_from_cl_kernel(const bf16* __restrict__ x, const bf16* __restrict__ mean,
+                                                             const bf16* __restrict__ inv_std, bf16* __restrict__ out, int Z,
+                                                             int Cx, int64_t thw) {
+    const int64_t total = thw * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % thw;
+        const int c = (int)(i / thw);
+        out[i] = (bf16)(rbf((float)x[pix * Cx + c] - (float)mean[c]) * (float)inv_std[c]);
     }
 }
 
@@ -242,23 +294,51 @@ int fg_vae_unpatchify_bf16(const void* x, void* video, int T, int H, int W, int 
     return fg_launch_status("fg_vae_unpatchify_bf16");
 }
 
-int fg_vae_tile_accumulate_bf16(const void* tile, void* values, void* weight, int F, int Hv, int Wv, int th, int tw, int y0,
-                                int x0, int border_h, int border_w, int bound_bits, fg_stream_t stream) {
-    FG_CHECK_ARG(tile && values && weight, "fg_vae_tile_accumulate_bf16: null pointer");
+int fg_vae_tile_accumulate_bf16(const void* tile, void* values, void* weight, int C, int F, int Hv, int Wv, int th, int tw,
+                                int y0, int x0, int border_h, int border_w, int bound_bits, fg_stream_t stream) {
+    FG_CHECK_ARG(tile && values && weight && C > 0, "fg_vae_tile_accumulate_bf16: null pointer");
     FG_CHECK_ARG(F > 0 && th > 0 && tw > 0 && y0 >= 0 && x0 >= 0 && y0 + th <= Hv && x0 + tw <= Wv && border_h >= 0 && border_w >= 0,
                  "fg_vae_tile_accumulate_bf16: tile does not fit the canvas");
     FG_CHECK_ARG(((bound_bits & 1) || border_h <= th) && ((bound_bits & 4) || border_w <= tw), "fg_vae_tile_accumulate_bf16: border wider than tile");
     hipLaunchKernelGGL(tile_accumulate_kernel, dim3(grid_for((int64_t)F * th * tw)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)tile, (bf16*)values, (bf16*)weight, F, Hv, Wv, th, tw, y0, x0, border_h, border_w, bound_bits);
+                       (const bf16*)tile, (bf16*)values, (bf16*)weight, C, F, Hv, Wv, th, tw, y0, x0, border_h, border_w, bound_bits);
     return fg_launch_status("fg_vae_tile_accumulate_bf16");
 }
 
-int fg_vae_tile_finalize_bf16(void* values, const void* weight, int F, int Hv, int Wv, fg_stream_t stream) {
-    FG_CHECK_ARG(values && weight && F > 0 && Hv > 0 && Wv > 0, "fg_vae_tile_finalize_bf16: bad arguments");
+int fg_vae_tile_finalize_bf16(void* values, const void* weight, int C, int F, int Hv, int Wv, int do_clamp, fg_stream_t stream) {
+    FG_CHECK_ARG(values && weight && C > 0 && F > 0 && Hv > 0 && Wv > 0, "fg_vae_tile_finalize_bf16: bad arguments");
     const int64_t fhw = (int64_t)F * Hv * Wv;
-    hipLaunchKernelGGL(tile_finalize_kernel, dim3(grid_for(3 * fhw)), dim3(256), 0, (hipStream_t)stream, (bf16*)values,
-                       (const bf16*)weight, fhw);
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3(grid_for(C * fhw)), dim3(256), 0, (hipStream_t)stream, (bf16*)values,
+                       (const bf16*)weight, C, fhw, do_clamp);
     return fg_launch_status("fg_vae_tile_finalize_bf16");
+}
+
+int fg_vae_patchify_bf16(const void* video, void* out, int T, int H, int W, fg_stream_t stream) {
+    FG_CHECK_ARG(video && out && T > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "fg_vae_patchify_bf16: bad arguments");
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((int64_t)T * H * W * 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)video,
+                       (bf16*)out, T, H / 2, W / 2);
+    return fg_launch_status("fg_vae_patchify_bf16");
+}
+
+int fg_avgdown3d_add_bf16(const void* x, const void* main_path, void* out, int T, int H, int W, int Cin, int Cout, int ft, int fs,
+                          fg_stream_t stream) {
+    FG_CHECK_ARG(x && main_path && out, "fg_avgdown3d_add_bf16: null pointer");
+    FG_CHECK_ARG(T > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (ft == 1 || ft == 2) && (fs == 1 || fs == 2) && H % fs == 0 &&
+                     W % fs == 0 && (Cin * ft * fs * fs) % Cout == 0,
+                 "fg_avgdown3d_add_bf16: bad sizes");
+    const int64_t total = (int64_t)((T + ft - 1) / ft) * (H / fs) * (W / fs) * Cout;
+    hipLaunchKernelGGL(avgdown3d_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)main_path, (bf16*)out, T, H, W, Cin, Cout, ft, fs);
+    return fg_launch_status("fg_avgdown3d_add_bf16");
+}
+
+int fg_vae_latent_from_cl_bf16(const void* x, const void* mean, const void* inv_std, void* out, int Z, int Cx, int T, int H, int W,
+                               fg_stream_t stream) {
+    FG_CHECK_ARG(x && mean && inv_std && out && Z > 0 && Cx >= Z && T > 0 && H > 0 && W > 0, "fg_vae_latent_from_cl_bf16: bad arguments");
+    const int64_t thw = (int64_t)T * H * W;
+    hipLaunchKernelGGL(latent_from_cl_kernel, dim3(grid_for(thw * Z)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)mean, (const bf16*)inv_std, (bf16*)out, Z, Cx, thw);
+    return fg_launch_status("fg_vae_latent_from_cl_bf16");
 }
 
 int fg_video_to_uint8(const void* video, void* out_u8, int F, int H, int W, fg_stream_t stream) {

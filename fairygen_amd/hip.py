@@ -34,8 +34,11 @@ _SIGNATURES = {
     "fg_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i64, _f32, _vp],
     "fg_vae_latent_to_cl_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "fg_vae_unpatchify_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
-    "fg_vae_tile_accumulate_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
-    "fg_vae_tile_finalize_bf16": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "fg_vae_tile_accumulate_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_tile_finalize_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_patchify_bf16": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "fg_avgdown3d_add_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fg_vae_latent_from_cl_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "fg_video_to_uint8": [_vp, _vp, _i32, _i32, _i32, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice"])
@@ -287,13 +290,15 @@ def conv_pack_weight(w):
     return packed
 
 
-def conv3d_cl(x, w_packed, bias, cout, kt, ks, residual=None, upsample2x=False, time_interleave=False, out=None):
+def conv3d_cl(x, w_packed, bias, cout, kt, ks, residual=None, upsample2x=False, time_interleave=False, out=None,
+              downsample2x=False):
     """x (T + kt-1, Hin, Win, Cin) channels-last, the first kt-1 frames being the causal history (feature cache)
     -> (T,H,W,Cout) [or (2T,H,W,Cout/2) with time_interleave]."""
     _dev(x, "x"), _dev(w_packed, "w_packed"), _dev(bias, "bias")
     assert x.dim() == 4 and x.is_contiguous() and x.shape[0] > kt - 1
     t, hin, win, cin = x.shape[0] - (kt - 1), x.shape[1], x.shape[2], x.shape[3]
-    h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
+    assert not (upsample2x and downsample2x)
+    h, w = (hin * 2, win * 2) if upsample2x else ((hin // 2, win // 2) if downsample2x else (hin, win))
     oshape = (2 * t, h, w, cout // 2) if time_interleave else (t, h, w, cout)
     out = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else out
     assert tuple(out.shape) == oshape and out.is_contiguous()
@@ -301,7 +306,7 @@ def conv3d_cl(x, w_packed, bias, cout, kt, ks, residual=None, upsample2x=False, 
         _dev(residual, "residual")
         assert tuple(residual.shape) == oshape and residual.is_contiguous()
     _call("fg_conv3d_cl_bf16", _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(out), t, h, w,
-          cin, cout, kt, ks, int(upsample2x), int(time_interleave), _stream(x))
+          cin, cout, kt, ks, 1 if upsample2x else (2 if downsample2x else 0), int(time_interleave), _stream(x))
     return out
 
 
@@ -347,18 +352,48 @@ def vae_unpatchify(x, video, t0, clamp):
 
 def vae_tile_accumulate(tile, values, weight, y0, x0, border_h, border_w, bounds):
     _dev(tile, "tile"), _dev(values, "values"), _dev(weight, "weight")
-    _, f, th, tw = tile.shape
+    c, f, th, tw = tile.shape
     _, _, hv, wv = values.shape
-    assert tile.is_contiguous() and values.is_contiguous() and weight.is_contiguous()
+    assert tile.is_contiguous() and values.is_contiguous() and weight.is_contiguous() and values.shape[0] == c
     bits = sum(1 << i for i, bnd in enumerate(bounds) if bnd)
-    _call("fg_vae_tile_accumulate_bf16", _ptr(tile), _ptr(values), _ptr(weight), f, hv, wv, th, tw, y0, x0,
+    _call("fg_vae_tile_accumulate_bf16", _ptr(tile), _ptr(values), _ptr(weight), c, f, hv, wv, th, tw, y0, x0,
           border_h, border_w, bits, _stream(tile))
 
 
-def vae_tile_finalize(values, weight):
-    _, f, hv, wv = values.shape
-    _call("fg_vae_tile_finalize_bf16", _ptr(values), _ptr(weight), f, hv, wv, _stream(values))
+def vae_tile_finalize(values, weight, clamp=True):
+    c, f, hv, wv = values.shape
+    _call("fg_vae_tile_finalize_bf16", _ptr(values), _ptr(weight), c, f, hv, wv, int(clamp), _stream(values))
     return values
+
+
+def vae_patchify(video):
+    """(3,T,H,W) -> (T,H/2,W/2,16) channels-last (12 patch channels + 4 zero channels)."""
+    _dev(video, "video")
+    assert video.dim() == 4 and video.shape[0] == 3 and video.is_contiguous()
+    _, t, h, w = video.shape
+    out = torch.empty((t, h // 2, w // 2, 16), dtype=video.dtype, device=video.device)
+    _call("fg_vae_patchify_bf16", _ptr(video), _ptr(out), t, h, w, _stream(video))
+    return out
+
+
+def avgdown3d_add(x, main, ft, fs):
+    _dev(x, "x"), _dev(main, "main")
+    t, h, w, cin = x.shape
+    cout = main.shape[-1]
+    assert tuple(main.shape) == ((t + ft - 1) // ft, h // fs, w // fs, cout) and x.is_contiguous() and main.is_contiguous()
+    out = torch.empty_like(main)
+    _call("fg_avgdown3d_add_bf16", _ptr(x), _ptr(main), _ptr(out), t, h, w, cin, cout, ft, fs, _stream(x))
+    return out
+
+
+def vae_latent_from_cl(x, mean, inv_std, z_dim):
+    """(T,h,w,Cx) -> (z_dim,T,h,w) normalised latent."""
+    _dev(x, "x"), _dev(mean, "mean"), _dev(inv_std, "inv_std")
+    t, h, w, cx = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((z_dim, t, h, w), dtype=x.dtype, device=x.device)
+    _call("fg_vae_latent_from_cl_bf16", _ptr(x), _ptr(mean), _ptr(inv_std), _ptr(out), z_dim, cx, t, h, w, _stream(x))
+    return out
 
 
 def video_to_uint8(video):

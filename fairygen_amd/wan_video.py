@@ -11,8 +11,8 @@ Animate, FunControl, camera, LongCat) are out of scope and their kwargs raise.
 Extensions (the only additions to the call surface, both optional):
   * ``prompt`` / ``negative_prompt`` may be pre-embedded context tensors ``(1, L, text_dim)`` — the umT5
     encoder + tokenizer are a later §8(f) row and need downloaded assets;
-  * ``first_frame_latents=`` supplies the TI2V conditioning latent directly while the VAE encoder row is
-    pending (``input_image`` then needs ``pipe.vae.encode``).
+  * ``first_frame_latents=`` supplies the TI2V conditioning latent directly (bench / tests); ``input_image=`` goes
+    through ``pipe.vae.encode`` (VAE38 encoder on the same HIP kernels) exactly like the reference.
 """
 import numpy as np
 import torch
@@ -106,7 +106,7 @@ class WanVideoUnit_InputVideoEmbedder(PipelineUnit):
 
     def process(self, pipe, input_video, noise):
         if input_video is not None:
-            raise NotImplementedError("video-to-video needs the VAE encoder (next hot-path row)")
+            raise NotImplementedError("video-to-video (multi-frame VAE encode) is not on the FairyGen inference path")
         return {"latents": noise}
 
 

@@ -171,7 +171,8 @@ class _ConvState:
         """View (t,h,w,cin) of the ring where the producer writes this chunk's input."""
         if self.ring is None or self.ring.shape[0] < t + CACHE_T or tuple(self.ring.shape[1:3]) != (h, w):
             old = self.ring
-            self.ring = torch.zeros((t + CACHE_T, h, w, self.cin), dtype=dtype, device=device)
+            cin = self.cin if self.cin % 8 == 0 else (self.cin + 15) // 16 * 16     # encoder conv1: 12 -> 16 (zero padded)
+            self.ring = torch.zeros((t + CACHE_T, h, w, cin), dtype=dtype, device=device)
             if old is not None and tuple(old.shape[1:3]) == (h, w):
                 self.ring[:CACHE_T].copy_(old[:CACHE_T])
         return self.ring[CACHE_T:CACHE_T + t]
@@ -186,7 +187,7 @@ class VideoVAE38_(nn.Module):
     def __init__(self, dim=160, z_dim=48, dec_dim=256, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
                  temperal_downsample=[False, True, True], dropout=0.0):
         super().__init__()
-        self.dim, self.z_dim, self.dim_mult = dim, z_dim, dim_mult
+        self.dim, self.dim_mult = dim, dim_mult
         self.temperal_downsample = temperal_downsample
         self.temperal_upsample = temperal_downsample[::-1]
         self.encoder = Encoder3d_38(dim, z_dim * 2, dim_mult, num_res_blocks, attn_scales, temperal_downsample, dropout)
@@ -194,6 +195,7 @@ class VideoVAE38_(nn.Module):
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d_38(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._conv_states = None
+        self.z_dim = z_dim
         self.max_chunk_group = 4      # latent frames per decoder call after the first (1 = the reference's chunking)
 
     # ------------------------------------------------------------------ weight preparation
@@ -210,22 +212,24 @@ class VideoVAE38_(nn.Module):
         self.invalidate_packed()
         return out
 
-    def _states(self):
+    def _states(self, encoder=False):
         if self._conv_states is None:
-            st = {}
-            for mod in [self.conv2] + [m for m in self.decoder.modules() if isinstance(m, (CausalConv3d, nn.Conv2d))]:
+            self._conv_states = {}
+        probe = self.conv1 if encoder else self.conv2
+        if id(probe) not in self._conv_states:      # decoder and encoder weights are packed on first use of each
+            root = self.encoder if encoder else self.decoder
+            for mod in [probe] + [m for m in root.modules() if isinstance(m, (CausalConv3d, nn.Conv2d))]:
                 if mod.weight.shape[-1] == 1 and mod.weight.dim() == 4:
                     continue        # 1x1 Conv2d of the AttentionBlock: plain GEMMs (F.linear)
-                st[id(mod)] = _ConvState(mod)
-            self._conv_states = st
+                self._conv_states[id(mod)] = _ConvState(mod)
         return self._conv_states
 
     # ------------------------------------------------------------------ building blocks (channels-last)
-    def _conv(self, conv, x, residual=None, upsample2x=False, time_interleave=False):
-        """Conv without temporal extent (1x1x1 shortcut, conv2, the 3x3 Conv2d after upsampling)."""
+    def _conv(self, conv, x, residual=None, upsample2x=False, time_interleave=False, downsample2x=False):
+        """Conv without temporal extent (1x1x1 shortcut / conv1 / conv2, the 3x3 Conv2d of the resamplers)."""
         st = self._states()[id(conv)]
         return hip.conv3d_cl(x, st.packed, st.bias, st.cout, st.kt, st.ks, residual=residual, upsample2x=upsample2x,
-                             time_interleave=time_interleave)
+                             time_interleave=time_interleave, downsample2x=downsample2x)
 
     def _slot(self, conv, like, t=None):
         """Where the producer of `conv`'s input must write: a (T,H,W,Cin) view inside the conv's ring."""
@@ -320,8 +324,39 @@ class VideoVAE38_(nn.Module):
         self.clear_cache()
         return video.unsqueeze(0)
 
+    def _resample_down(self, rs, x):
+        x = self._conv(rs.resample[1], x, downsample2x=True)
+        # downsample3d on the first chunk only stores its cache and skips time_conv (reference :163-167)
+        return x
+
     def encode(self, x, scale):
-        raise NotImplementedError("VAE38 encoder is the next hot-path row (SURVEY.md §8f-2); pass first_frame_latents=")
+        """First-frame conditioning: x (1,3,1,H,W) in [-1,1] on the HIP device -> mu (1,48,1,H/16,W/16), normalised
+        (reference :1298-1323 with t == 1: a single encoder chunk, no temporal down-convolution)."""
+        assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3
+        if x.shape[2] != 1:
+            raise NotImplementedError("multi-frame (video-to-video) encode is not on the FairyGen inference path")
+        self._states(encoder=True)
+        self.clear_cache()
+        enc = self.encoder
+        mean, inv_std = (s.to(dtype=x.dtype, device=x.device).contiguous() for s in scale)
+        y = hip.vae_patchify(x[0].contiguous())
+        self._slot(enc.conv1, y).copy_(y)
+        y = self._cconv(enc.conv1, 1)
+        for blk in enc.downsamples:
+            y_copy = y
+            for layer in blk.downsamples:
+                y = self._res(layer, y) if isinstance(layer, ResidualBlock) else self._resample_down(layer, y)
+            sc = blk.avg_shortcut
+            y = hip.avgdown3d_add(y_copy, y, sc.factor_t, sc.factor_s)
+        y = self._res(enc.middle[0], y)
+        y = self._attn(enc.middle[1], y)
+        y = self._res(enc.middle[2], y)
+        hip.vae_rmsnorm_silu(y, enc.head[0].gamma.view(-1), True, out=self._slot(enc.head[2], y))
+        y = self._cconv(enc.head[2], 1)
+        y = self._conv(self.conv1, y)
+        mu = hip.vae_latent_from_cl(y, mean, inv_std, self.z_dim)
+        self.clear_cache()
+        return mu.unsqueeze(0)
 
 
 class WanVideoVAE38(nn.Module):
@@ -401,5 +436,31 @@ class WanVideoVAE38(nn.Module):
             videos.append(video.squeeze(0))
         return torch.stack(videos)
 
+    def tiled_encode(self, video, device, tile_size, tile_stride):
+        """(1,3,T,H,W) -> (1,48,T',H/16,W/16): pixel-space tiles, latent-space feathering (:1155-1203)."""
+        _, _, T, H, W = video.shape
+        up = self.upsampling_factor
+        out_T = (T + 3) // 4
+        video = video.to(device)
+        weight = torch.zeros((1, 1, out_T, H // up, W // up), dtype=video.dtype, device=device)
+        values = torch.zeros((1, self.z_dim, out_T, H // up, W // up), dtype=video.dtype, device=device)
+        for h, h_, w, w_ in self.tile_tasks(H, W, tile_size, tile_stride):
+            tile = self.model.encode(video[:, :, :, h:h_, w:w_].contiguous(), self.scale)
+            hip.vae_tile_accumulate(tile[0], values[0], weight[0, 0], h // up, w // up,
+                                    (tile_size[0] - tile_stride[0]) // up, (tile_size[1] - tile_stride[1]) // up,
+                                    (h == 0, h_ >= H, w == 0, w_ >= W))
+        hip.vae_tile_finalize(values[0], weight[0, 0], clamp=False)
+        return values
+
     def encode(self, videos, device, tiled=False, tile_size=(34, 34), tile_stride=(18, 16)):
-        return self.model.encode(videos, self.scale)
+        """list of (3,T,H,W) in [-1,1] -> (B,48,T',H/16,W/16) on `device` (:1218-1232)."""
+        outs = []
+        for video in videos:
+            video = video.unsqueeze(0).to(device)
+            if tiled:
+                up = self.upsampling_factor
+                z = self.tiled_encode(video, device, (tile_size[0] * up, tile_size[1] * up), (tile_stride[0] * up, tile_stride[1] * up))
+            else:
+                z = self.model.encode(video, self.scale)
+            outs.append(z.squeeze(0))
+        return torch.stack(outs)

@@ -122,8 +122,9 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
                              fg_stream_t stream);
 
 /* Causal conv as implicit GEMM on MFMA: CausalConv3d.forward models/wan_video_vae.py:33-52 (kt in {1,3},
- * kh==kw in {1,3}, stride 1, "same" spatial zero padding, causal time padding) and the Conv2d after
- * nearest-exact 2x upsampling in Resample38 (:242-251) when upsample2x!=0 (input is (.,H/2,W/2,Cin)).
+ * kh==kw in {1,3}, stride 1, "same" spatial zero padding, causal time padding); resample == 1: the Conv2d after
+ * nearest-exact 2x upsampling in Resample38 (:242-251; input is (.,H/2,W/2,Cin)); resample == 2: the encoder's
+ * ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2) of Resample38 downsample (:253-263; input is (.,2H,2W,Cin)).
  * x: (T + kt-1, Hin, Win, Cin) — the first kt-1 frames are the layer's feature cache, i.e. the previous input
  * frames that the reference concatenates in front (:46-49), zeros on the first chunk / after 'Rep'; output frame
  * t reads input frames t .. t+kt-1.  out (T,H,W,Cout), or with time_interleave!=0 (Resample.forward :153-156,
@@ -133,7 +134,7 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
 int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias,
                       const void* residual, void* out,
                       int T, int H, int W, int Cin, int Cout, int kt, int ks,
-                      int upsample2x, int time_interleave, fg_stream_t stream);
+                      int resample, int time_interleave, fg_stream_t stream);
 
 /* out = main + DupUp3D(x): models/wan_video_vae.py:417-439,510-512.  x (T,H,W,Cin); main/out
  * (T*ft - drop, H*fs, W*fs, Cout) where drop = ft-1 if first_chunk. */
@@ -160,13 +161,29 @@ int fg_vae_unpatchify_bf16(const void* x, void* video, int T, int H, int W, int 
 /* Tiled-decode feathering (WanVideoVAE.tiled_decode models/wan_video_vae.py:1124-1149, masks :1081-1100):
  * values[:, :, y0:y0+th, x0:x0+tw] += tile*mask ; weight[...] += mask, bf16 accumulators like the
  * reference; mask(y,x) = min(ramp_h(y), ramp_w(x)), ramps of width border_h/border_w on non-bound sides.
- * values (3,F,Hv,Wv), weight (F,Hv,Wv), tile (3,F,th,tw). bound bits: 1 top, 2 bottom, 4 left, 8 right. */
+ * values (C,F,Hv,Wv), weight (F,Hv,Wv), tile (C,F,th,tw) (C = 3 decode, 48 tiled_encode :1176-1201).
+ * bound bits: 1 top, 2 bottom, 4 left, 8 right. */
 int fg_vae_tile_accumulate_bf16(const void* tile, void* values, void* weight,
-                                int F, int Hv, int Wv, int th, int tw, int y0, int x0,
+                                int C, int F, int Hv, int Wv, int th, int tw, int y0, int x0,
                                 int border_h, int border_w, int bound_bits, fg_stream_t stream);
 
-/* values = clamp(values / weight, -1, 1) (models/wan_video_vae.py:1150-1151). */
-int fg_vae_tile_finalize_bf16(void* values, const void* weight, int F, int Hv, int Wv, fg_stream_t stream);
+/* values = values / weight, clamped to [-1,1] when do_clamp (decode :1150-1151; encode :1202 does not clamp). */
+int fg_vae_tile_finalize_bf16(void* values, const void* weight, int C, int F, int Hv, int Wv, int do_clamp,
+                              fg_stream_t stream);
+
+/* Encoder boundary (first-frame conditioning, VideoVAE38_.encode models/wan_video_vae.py:1298-1323):
+ * video (3,T,H,W) NCTHW -> patchify(.,2) (:199-211) -> channels-last (T,H/2,W/2,16): 12 channels + 4 zeros, so the
+ * 12->dim conv1 reads whole 16-byte chunks (its packed weights are zero beyond channel 12). */
+int fg_vae_patchify_bf16(const void* video, void* out, int T, int H, int W, fg_stream_t stream);
+
+/* out = main + AvgDown3D(x): Down_ResidualBlock shortcut (models/wan_video_vae.py:363-395,474).  x (T,H,W,Cin);
+ * main/out (ceil(T/ft),H/fs,W/fs,Cout); a missing leading frame counts as zeros (the reference pads in front). */
+int fg_avgdown3d_add_bf16(const void* x, const void* main_path, void* out,
+                          int T, int H, int W, int Cin, int Cout, int ft, int fs, fg_stream_t stream);
+
+/* Encoder tail (:1314-1321): x (T,H,W,Cx) channels-last, mu = first Z channels; out (Z,T,H,W) = (mu - mean) * inv_std. */
+int fg_vae_latent_from_cl_bf16(const void* x, const void* mean, const void* inv_std, void* out,
+                               int Z, int Cx, int T, int H, int W, fg_stream_t stream);
 
 /* (3,F,H,W) bf16 in [-1,1] -> (F,H,W,3) uint8 by ((x+1)*127.5).clip(0,255) truncation
  * (BasePipeline.vae_output_to_video, diffusion/base_pipeline.py:128-143). */

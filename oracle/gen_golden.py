@@ -202,13 +202,22 @@ def main():
         out["tiled_bf16"] = wrap.decode(z, device="cpu", tiled=True, tile_size=(3, 4), tile_stride=(2, 2))
         w32 = wrap.float()
         out["decode_f32"] = w32.decode(z.float(), device="cpu", tiled=False)
+        # encoder: first-frame image (the TI2V conditioning path), a 9-frame video (chunked encode), tiled image
+        img = seeded((3, 1, 64, 96), 32, scale=0.5).clamp(-1, 1)
+        vid = seeded((3, 9, 64, 96), 33, scale=0.5).clamp(-1, 1)
+        wb = wrap.to(torch.bfloat16)
+        out["encode_image_bf16"] = wb.encode([img], device="cpu")
+        out["encode_video_bf16"] = wb.encode([vid], device="cpu")
+        out["encode_image_tiled_bf16"] = wb.encode([img], device="cpu", tiled=True, tile_size=(3, 4), tile_stride=(2, 2))
+        out["encode_image_f32"] = wb.float().encode([img.float()], device="cpu")
     # the class constants the wrapper was built from must be the reference's
     ref_full_src = open("/root/reference/animation/diffsynth/models/wan_video_vae.py").read()
     assert "-0.2289, -0.0052, -0.1323" in ref_full_src and "0.4765, 1.0364, 0.4514" in ref_full_src
     save("vae_tiny.safetensors", out, {
         "config": f"VideoVAE38_(dim={dim}, z_dim=48, dec_dim={dec_dim})",
         "weights": f"synthetic.random_state_dict(vae_shapes(dec_dim={dec_dim}, dim={dim}), seed=1234)",
-        "inputs": "z=seeded((1,48,3,4,6),31); tiled: tile_size=(3,4) tile_stride=(2,2)",
+        "inputs": "z=seeded((1,48,3,4,6),31); tiled: tile_size=(3,4) tile_stride=(2,2); encode: img=seeded((3,1,64,96),32,scale=0.5).clamp(-1,1), "
+                  "vid=seeded((3,9,64,96),33,scale=0.5).clamp(-1,1)",
         "source": "diffsynth/models/wan_video_vae.py WanVideoVAE.decode/tiled_decode :1103-1152,1235-1247; VideoVAE38_.decode :1326-1351"})
 
     # ------------------------------------------------------------------ 6. pixel / noise conventions

@@ -244,3 +244,132 @@ def vae_decode(sd, latents, tiled=False, tile_size=(34, 34), tile_stride=(18, 16
         v = tiled_decode(sd, z, tile_size, tile_stride) if tiled else decode(sd, z).clamp_(-1, 1)
         vids.append(v.squeeze(0))
     return torch.stack(vids)
+
+
+# ------------------------------------------------------------------------------------------- encoder (first-frame path)
+def patchify2(x):
+    """wan_video_vae.py:199-211 with patch 2: 'b c f (h q) (w r) -> b (c r q) f h w'."""
+    b, c, f, H, W = x.shape
+    x = x.view(b, c, f, H // 2, 2, W // 2, 2).permute(0, 1, 6, 4, 2, 3, 5)     # b c r q f h w
+    return x.reshape(b, c * 4, f, H // 2, W // 2)
+
+
+def avg_down3d(x, out_channels, factor_t, factor_s):
+    """AvgDown3D.forward, wan_video_vae.py:363-395."""
+    pad_t = (factor_t - x.shape[2] % factor_t) % factor_t
+    x = F.pad(x, (0, 0, 0, 0, pad_t, 0))
+    B, C, T, H, W = x.shape
+    factor = factor_t * factor_s * factor_s
+    x = x.view(B, C, T // factor_t, factor_t, H // factor_s, factor_s, W // factor_s, factor_s)
+    x = x.permute(0, 1, 3, 5, 7, 2, 4, 6).contiguous()
+    x = x.view(B, C * factor, T // factor_t, H // factor_s, W // factor_s)
+    x = x.view(B, out_channels, C * factor // out_channels, T // factor_t, H // factor_s, W // factor_s)
+    return x.mean(dim=2)
+
+
+def resample_down(sd, p, x, cache, idx, temporal):
+    """Resample.forward downsample2d / downsample3d, wan_video_vae.py:157-174 (+ Resample38 :253-263)."""
+    b, c, t, h, w = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    y = F.conv2d(F.pad(y, (0, 1, 0, 1)), sd[p + ".resample.1.weight"], sd[p + ".resample.1.bias"], stride=2)
+    x = y.view(b, t, c, y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+    if temporal:
+        i = idx[0]
+        if cache[i] is None:
+            cache[i] = x.clone()
+            idx[0] += 1
+        else:
+            new_cache = x[:, :, -1:].clone()
+            w_, b_ = sd[p + ".time_conv.weight"], sd[p + ".time_conv.bias"]
+            x = F.conv3d(torch.cat([cache[i][:, :, -1:], x], 2), w_, b_, stride=(2, 1, 1))
+            cache[i] = new_cache
+            idx[0] += 1
+    return x
+
+
+def encoder_config(sd, prefix="model.encoder"):
+    dims = [sd[prefix + ".conv1.weight"].shape[0]]
+    i = 0
+    while f"{prefix}.downsamples.{i}.downsamples.0.residual.2.weight" in sd:
+        dims.append(sd[f"{prefix}.downsamples.{i}.downsamples.0.residual.2.weight"].shape[0])
+        i += 1
+    n = i
+    has_down = [f"{prefix}.downsamples.{j}.downsamples.2.resample.1.weight" in sd for j in range(n)]
+    temporal = [f"{prefix}.downsamples.{j}.downsamples.2.time_conv.weight" in sd for j in range(n)]
+    return dims, has_down, temporal
+
+
+def encoder_chunk(sd, x, cache, prefix="model.encoder"):
+    """Encoder3d_38.forward, wan_video_vae.py:679-733."""
+    idx = [0]
+    dims, has_down, temporal = encoder_config(sd, prefix)
+    new_cache = _roll_cache(x, cache[0])
+    x = causal_conv3d(sd, prefix + ".conv1", x, cache[0])
+    cache[0] = new_cache
+    idx[0] = 1
+    for j in range(len(dims) - 1):
+        p = f"{prefix}.downsamples.{j}"
+        x_copy = x.clone()
+        for r in range(2):
+            x = residual_block(sd, f"{p}.downsamples.{r}", x, cache, idx)
+        if has_down[j]:
+            x = resample_down(sd, f"{p}.downsamples.2", x, cache, idx, temporal[j])
+        x = x + avg_down3d(x_copy, dims[j + 1], 2 if temporal[j] else 1, 2 if has_down[j] else 1)
+    x = residual_block(sd, prefix + ".middle.0", x, cache, idx)
+    x = attention_block(sd, prefix + ".middle.1", x)
+    x = residual_block(sd, prefix + ".middle.2", x, cache, idx)
+    x = F.silu(rms_norm_c(sd, prefix + ".head.0", x))
+    new_cache = _roll_cache(x, cache[idx[0]])
+    x = causal_conv3d(sd, prefix + ".head.2", x, cache[idx[0]])
+    cache[idx[0]] = new_cache
+    return x
+
+
+def encode(sd, x, mean=None, std=None, prefix="model"):
+    """VideoVAE38_.encode, wan_video_vae.py:1298-1323: video (1,3,T,H,W) in [-1,1] -> mu (1,48,(T+3)//4,H/16,W/16)."""
+    x = patchify2(x)
+    t = x.shape[2]
+    cache = [None] * count_causal_convs(sd, prefix + ".encoder")
+    outs = []
+    for i in range(1 + (t - 1) // 4):
+        chunk = x[:, :, :1] if i == 0 else x[:, :, 1 + 4 * (i - 1):1 + 4 * i]
+        outs.append(encoder_chunk(sd, chunk, cache, prefix + ".encoder"))
+    out = torch.cat(outs, 2)
+    mu, _ = causal_conv3d(sd, prefix + ".conv1", out).chunk(2, dim=1)
+    zc = mu.shape[1]
+    mean = torch.tensor(VAE38_MEAN if mean is None else mean).to(mu.dtype)
+    inv_std = (1.0 / torch.tensor(VAE38_STD if std is None else std)).to(mu.dtype)
+    return (mu - mean.view(1, zc, 1, 1, 1)) * inv_std.view(1, zc, 1, 1, 1)
+
+
+def tiled_encode(sd, video, tile_size, tile_stride, upsampling=16, prefix="model"):
+    """WanVideoVAE.tiled_encode, wan_video_vae.py:1155-1203 (tile sizes in pixels)."""
+    _, _, T, H, W = video.shape
+    out_T = (T + 3) // 4
+    zc = sd[prefix + ".conv2.weight"].shape[0]
+    weight = torch.zeros((1, 1, out_T, H // upsampling, W // upsampling), dtype=video.dtype)
+    values = torch.zeros((1, zc, out_T, H // upsampling, W // upsampling), dtype=video.dtype)
+    for h, h_, w, w_ in tile_tasks(H, W, tile_size, tile_stride):
+        tile = encode(sd, video[:, :, :, h:h_, w:w_], prefix=prefix)
+        m = tile_mask(tile.shape[3], tile.shape[4], (h == 0, h_ >= H, w == 0, w_ >= W),
+                      ((tile_size[0] - tile_stride[0]) // upsampling, (tile_size[1] - tile_stride[1]) // upsampling))
+        m = m.to(dtype=video.dtype)
+        th, tw = h // upsampling, w // upsampling
+        values[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += tile * m
+        weight[:, :, :, th:th + tile.shape[3], tw:tw + tile.shape[4]] += m
+    return values / weight
+
+
+def vae_encode(sd, videos, tiled=False, tile_size=(34, 34), tile_stride=(18, 16), upsampling=16):
+    """WanVideoVAE.encode, wan_video_vae.py:1218-1232: list of (3,T,H,W) -> (B,48,T',h,w)."""
+    outs = []
+    for video in videos:
+        video = video.unsqueeze(0)
+        if tiled:
+            ts = (tile_size[0] * upsampling, tile_size[1] * upsampling)
+            st = (tile_stride[0] * upsampling, tile_stride[1] * upsampling)
+            z = tiled_encode(sd, video, ts, st, upsampling)
+        else:
+            z = encode(sd, video)
+        outs.append(z.squeeze(0))
+    return torch.stack(outs)

@@ -131,6 +131,25 @@ def test_tiny_vae_decode_vs_golden(tiny_vae, golden):
     assert cos(out_t, g["tiled_bf16"]) > 0.9995
 
 
+def test_tiny_vae_encode_vs_golden(tiny_vae, golden):
+    """First-frame conditioning path: WanVideoVAE38.encode([image]) untiled and tiled."""
+    g = golden("vae_tiny.safetensors")
+    vae, sd = tiny_vae
+    img = seeded((3, 1, 64, 96), 32, scale=0.5).clamp(-1, 1)
+    ref32 = g["encode_image_f32"]
+    err_ref = (g["encode_image_bf16"].float() - ref32).abs().max().item()
+    with torch.no_grad():
+        z = vae.encode([img.cuda()], device="cuda")
+        zt = vae.encode([img.cuda()], device="cuda", tiled=True, tile_size=(3, 4), tile_stride=(2, 2))
+    assert z.shape == ref32.shape == zt.shape
+    err = (z.float().cpu() - ref32).abs().max().item()
+    assert err <= 2 * err_ref + 2e-2, (err, err_ref)
+    assert cos(z, g["encode_image_bf16"]) > 0.9995 and cos(zt, g["encode_image_tiled_bf16"]) > 0.9995
+    assert (zt.float().cpu() - g["encode_image_tiled_bf16"].float()).abs().max().item() <= 2 * err_ref + 4e-2
+    with pytest.raises(NotImplementedError):
+        vae.encode([seeded((3, 5, 64, 96), 1).cuda()], device="cuda")
+
+
 def test_fullwidth_vae_decoder_small_latent_vs_oracle():
     """The real decoder widths (dec_dim 256: 1024/1024/1024/512/256 channels, 34 causal convs) on a small latent."""
     from fairygen_amd.wan_video_vae import WanVideoVAE38
@@ -189,3 +208,16 @@ def test_pipeline_call_end_to_end(tmp_path, tiny_vae):
     import numpy as np
     got = np.stack([np.array(f) for f in frames]).astype("int32")
     assert np.abs(got - want).mean() <= 1.0, np.abs(got - want).mean()
+    # the reference's own TI2V entry: input_image= (PIL) -> VAE38 encode -> first-frame latent
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    pil = Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8))
+    frames2 = pipe(prompt=ctx_p, negative_prompt=ctx_n, input_image=pil, seed=1, height=64, width=64, num_frames=9,
+                   num_inference_steps=2, tiled=False, progress_bar_cmd=lambda x: x)
+    assert len(frames2) == 9
+    img_t = torch.Tensor(np.array(pil, dtype=np.float32)).to(torch.bfloat16) * (2 / 255) - 1          # preprocess_image
+    z_img = wan_vae.vae_encode(vsd_p, [img_t.permute(2, 0, 1).unsqueeze(1)])
+    lat2, vid2 = opipe.generate_clip(dsd, cfg, vsd_p, noise, ctx_p, ctx_n, 2, 5.0, 5.0, z_img, False)
+    got2 = np.stack([np.array(f) for f in frames2]).astype("int32")
+    want2 = opipe.video_to_uint8(vid2[0]).numpy().astype("int32")
+    assert np.abs(got2 - want2).mean() <= 1.5, np.abs(got2 - want2).mean()

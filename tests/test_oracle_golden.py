@@ -91,6 +91,18 @@ def test_vae_tiny_decode(golden):
     assert torch.allclose(wan_vae.vae_decode(sd32, z.float(), tiled=False), g["decode_f32"], atol=1e-5, rtol=1e-5)
 
 
+def test_vae_tiny_encode(golden):
+    g = golden("vae_tiny.safetensors")
+    sd = synthetic.random_state_dict(synthetic.vae_shapes(dec_dim=32, dim=32), seed=1234)
+    img = seeded((3, 1, 64, 96), 32, scale=0.5).clamp(-1, 1)
+    vid = seeded((3, 9, 64, 96), 33, scale=0.5).clamp(-1, 1)
+    assert torch.equal(wan_vae.vae_encode(sd, [img]), g["encode_image_bf16"])
+    assert torch.equal(wan_vae.vae_encode(sd, [vid]), g["encode_video_bf16"])
+    assert torch.equal(wan_vae.vae_encode(sd, [img], True, (3, 4), (2, 2)), g["encode_image_tiled_bf16"])
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert torch.allclose(wan_vae.vae_encode(sd32, [img.float()]), g["encode_image_f32"], atol=1e-5, rtol=1e-5)
+
+
 def test_pixels_and_noise(golden):
     g = golden("pixels.safetensors")
     assert torch.equal(opipe.generate_noise((1, 48, 2, 4, 4), 1), g["noise_seed1"])
