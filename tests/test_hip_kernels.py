@@ -268,6 +268,30 @@ def test_softmax_latent_unpatchify_uint8(hip):
     assert torch.equal(hip.video_to_uint8(dev(vid)).cpu(), opipe.video_to_uint8(vid))
 
 
+def test_encoder_kernels(hip):
+    """stride-2 conv (ZeroPad2d((0,1,0,1)) + Conv2d stride 2), patchify, AvgDown3D + add, latent tail."""
+    c = 64
+    x = seeded((1, c, 2, 10, 12), 110)
+    w2, b2 = seeded((c, c, 3, 3), 111, scale=(c * 9) ** -0.5), seeded((c,), 112, scale=0.1)
+    y = x[0].permute(1, 0, 2, 3)
+    want = F.conv2d(F.pad(y, (0, 1, 0, 1)), w2, b2, stride=2).permute(1, 0, 2, 3).unsqueeze(0)
+    got = hip.conv3d_cl(dev(_cl(x)), hip.conv_pack_weight(dev(w2)), dev(b2), c, 1, 3, downsample2x=True)
+    assert (_ncthw(got.cpu()).float() - want.float()).abs().max().item() < 3e-2
+    vid = seeded((1, 3, 2, 8, 12), 113, scale=0.5)
+    p = hip.vae_patchify(dev(vid[0].contiguous())).cpu()
+    assert torch.equal(_ncthw(p[..., :12]), wan_vae.patchify2(vid)) and not p[..., 12:].any()
+    for cin, cout, ft, fs, T in ((32, 32, 1, 2, 1), (32, 64, 2, 2, 1), (32, 64, 2, 2, 4), (64, 64, 1, 1, 2)):
+        xs = seeded((1, cin, T, 6, 8), 114)
+        sc = wan_vae.avg_down3d(xs, cout, ft, fs)
+        main = seeded(tuple(sc.shape), 115)
+        got = hip.avgdown3d_add(dev(_cl(xs)), dev(_cl(main)), ft, fs)
+        assert_close_bf16(_ncthw(got.cpu()), main + sc, 1.0, f"avgdown {cin}->{cout} ft{ft} fs{fs}", mag=main, max_mismatch=0.02)
+    mean, inv_std = torch.tensor(wan_vae.VAE38_MEAN).to(torch.bfloat16), (1.0 / torch.tensor(wan_vae.VAE38_STD)).to(torch.bfloat16)
+    h96 = seeded((1, 96, 1, 3, 5), 116)
+    want = (h96[:, :48] - mean.view(1, 48, 1, 1, 1)) * inv_std.view(1, 48, 1, 1, 1)
+    assert torch.equal(hip.vae_latent_from_cl(dev(_cl(h96)), dev(mean), dev(inv_std), 48).cpu().unsqueeze(0), want)
+
+
 def test_tile_blend(hip):
     H, W, up, T = 5, 7, 2, 2
     F_ = 4 * T - 3

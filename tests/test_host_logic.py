@@ -47,6 +47,21 @@ def test_argument_validation_through_the_c_abi():
     assert lib.fg_conv_packed_bytes(1024, 48, 3, 3, 3) == 27 * 1024 * 64 * 2
 
 
+def test_attention_split_choice_is_host_logic():
+    """The split-KV decomposition is chosen on the host from the shape alone (256 workgroup slots assumed without a GPU)."""
+    lib = hip.load()
+    R, S = ctypes.c_int(), ctypes.c_int()
+    def choice(nq, nkv, ws=1 << 40):
+        assert lib.fg_attn_split_choice(1, nq, nkv, 24, ws, ctypes.byref(R), ctypes.byref(S)) == 0
+        return R.value, S.value
+    assert choice(27280, 27280) == (1, 16)          # 2568 workgroups = 10.03 rounds: cut each head's tail q-block
+    assert choice(3410, 27280)[0] == 14             # a 1/8 token shard: every q-block is cut into KV ranges
+    assert choice(27280, 512) == (0, 1)             # cross-attention: 8 KV tiles, nothing to balance
+    assert choice(27280, 27280, ws=0) == (0, 1)     # no workspace -> no split
+    assert lib.fg_attn_workspace_bytes(1, 27280, 27280, 24) == 24 * 16 * (256 * 128 * 4 + 256 * 2 * 4)
+    assert lib.fg_attn_workspace_bytes(1, 27280, 512, 24) == 0
+
+
 def test_key_hashes_match_the_reference_table():
     # configs/model_configs.py:289-302 of the reference
     dit = {k: list(v) for k, v in synthetic.dit_shapes().items()}
