@@ -40,6 +40,8 @@ _SIGNATURES = {
     "fg_avgdown3d_add_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "fg_vae_latent_from_cl_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "fg_video_to_uint8": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "fg_softmax_bias_bf16": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "fg_gated_gelu_bf16": [_vp, _vp, _vp, _i64, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice"])
 
@@ -403,4 +405,26 @@ def video_to_uint8(video):
     _, f, h, w = video.shape
     out = torch.empty((f, h, w, 3), dtype=torch.uint8, device=video.device)
     _call("fg_video_to_uint8", _ptr(video), _ptr(out), f, h, w, _stream(video))
+    return out
+
+
+# ----------------------------------------------------------------------------- umT5 text encoder helpers
+def softmax_bias(scores, bias, key_mask=None):
+    """scores, bias (rows, cols) bf16; key_mask (cols,) int32 or None -> probs bf16."""
+    _dev(scores, "scores"), _dev(bias, "bias")
+    assert scores.dim() == 2 and scores.shape == bias.shape and scores.is_contiguous() and bias.is_contiguous()
+    if key_mask is not None:
+        _dev(key_mask, "key_mask", torch.int32)
+        assert key_mask.shape == (scores.shape[1],) and key_mask.is_contiguous()
+    probs = torch.empty_like(scores)
+    _call("fg_softmax_bias_bf16", _ptr(scores), _ptr(bias), _ptr(key_mask), _ptr(probs), scores.shape[0], scores.shape[1],
+          _stream(scores))
+    return probs
+
+
+def gated_gelu(fc1, gate):
+    _dev(fc1, "fc1"), _dev(gate, "gate")
+    assert fc1.shape == gate.shape and fc1.is_contiguous() and gate.is_contiguous()
+    out = torch.empty_like(fc1)
+    _call("fg_gated_gelu_bf16", _ptr(fc1), _ptr(gate), _ptr(out), fc1.numel(), _stream(fc1))
     return out

@@ -138,8 +138,13 @@ TI2V_5B_DIT_KWARGS = {
     "require_clip_embedding": False, "require_vae_embedding": False, "fuse_vae_embedding_in_latents": True,
 }
 
-# The two entries of diffsynth/configs/model_configs.py (:289-302) that the TI2V-5B hot path needs.
+# The entries of diffsynth/configs/model_configs.py (:92-96, :289-302) that the TI2V-5B path needs.
 MODEL_CONFIGS = [
+    {
+        "model_hash": "9c8818c2cbea55eca56c7b447df170da",       # models_t5_umt5-xxl-enc-bf16 (model_configs.py:92-96)
+        "model_name": "wan_video_text_encoder",
+        "model_class": "fairygen_amd.wan_video_text_encoder.WanTextEncoder",
+    },
     {
         "model_hash": "1f5ab7703c6fc803fdded85ff040c316",
         "model_name": "wan_video_dit",

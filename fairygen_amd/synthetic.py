@@ -26,6 +26,15 @@ def dit_shapes(kwargs=None):
         return _shapes(WanModel(**(kwargs or TI2V_5B_DIT_KWARGS)))
 
 
+TINY_TEXT_KWARGS = dict(vocab=100, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=2, num_buckets=32)
+
+
+def text_encoder_shapes(kwargs=None):
+    from .wan_video_text_encoder import WanTextEncoder
+    with torch.device("meta"):
+        return _shapes(WanTextEncoder(**(kwargs or {})))
+
+
 def vae_shapes(dec_dim=256, dim=160, with_prefix=True):
     with torch.device("meta"):
         shapes = _shapes(WanVideoVAE38(dim=dim, dec_dim=dec_dim))

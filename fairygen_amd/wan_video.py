@@ -9,8 +9,8 @@ Drop-in for what ``animation/inference.py:9-30`` touches of ``diffsynth/pipeline
 Animate, FunControl, camera, LongCat) are out of scope and their kwargs raise.
 
 Extensions (the only additions to the call surface, both optional):
-  * ``prompt`` / ``negative_prompt`` may be pre-embedded context tensors ``(1, L, text_dim)`` — the umT5
-    encoder + tokenizer are a later §8(f) row and need downloaded assets;
+  * ``prompt`` / ``negative_prompt`` may be pre-embedded context tensors ``(1, L, text_dim)`` (bench / tests: no
+    tokenizer assets offline); strings go through ``pipe.tokenizer`` + the umT5 encoder like in the reference;
   * ``first_frame_latents=`` supplies the TI2V conditioning latent directly (bench / tests); ``input_image=`` goes
     through ``pipe.vae.encode`` (VAE38 encoder on the same HIP kernels) exactly like the reference.
 """
@@ -89,8 +89,9 @@ class WanVideoUnit_PromptEmbedder(PipelineUnit):
         if isinstance(prompt, torch.Tensor):          # pre-embedded context (extension, see module docstring)
             return {"context": prompt.to(dtype=pipe.torch_dtype, device=pipe.device)}
         if pipe.text_encoder is None or pipe.tokenizer is None:
-            raise RuntimeError("no text encoder / tokenizer loaded (umT5 is a later hot-path row and needs downloaded "
-                               "assets): pass prompt= and negative_prompt= as (1, L, text_dim) context tensors")
+            raise RuntimeError("no text encoder / tokenizer loaded (pass the umT5 checkpoint in model_configs and "
+                               "tokenizer_config=ModelConfig(path=<local google/umt5-xxl dir>)), or pass prompt= and "
+                               "negative_prompt= as pre-embedded (1, L, text_dim) context tensors")
         ids, mask = pipe.tokenizer(prompt, return_mask=True, add_special_tokens=True)
         ids, mask = ids.to(pipe.device), mask.to(pipe.device)
         seq_lens = mask.gt(0).sum(dim=1).long()
@@ -183,9 +184,10 @@ class WanVideoPipeline(torch.nn.Module):
         pipe.vae = pool.fetch_model("wan_video_vae")
         if pipe.vae is not None:
             pipe.height_division_factor = pipe.width_division_factor = pipe.vae.upsampling_factor * 2
-        if tokenizer_config is not None:
+        if tokenizer_config is not None:      # reference default downloads google/umt5-xxl; here: ModelConfig(path=<local dir>)
             tokenizer_config.download_if_necessary()
-            raise NotImplementedError("HuggingfaceTokenizer plumbing arrives with the umT5 row; pass context tensors")
+            from .wan_video_text_encoder import HuggingfaceTokenizer
+            pipe.tokenizer = HuggingfaceTokenizer(name=tokenizer_config.path, seq_len=512, clean="whitespace")
         if use_usp:
             pipe.enable_usp()
         return pipe

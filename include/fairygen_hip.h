@@ -189,6 +189,20 @@ int fg_vae_latent_from_cl_bf16(const void* x, const void* mean, const void* inv_
  * (BasePipeline.vae_output_to_video, diffusion/base_pipeline.py:128-143). */
 int fg_video_to_uint8(const void* video, void* out_u8, int F, int H, int W, fg_stream_t stream);
 
+/* ------------------------------------------------------------------------ umT5 text encoder helpers
+ * (WanTextEncoder runs twice per clip before the loop; its GEMMs stay on hipBLASLt, T5LayerNorm is
+ * fg_rmsnorm_rope_bf16 without tables.) */
+
+/* T5Attention softmax, models/wan_video_text_encoder.py:72-87: probs = softmax over keys of
+ * bf16(scores + bias), bias replaced by finfo(bf16).min where key_mask[c] == 0 (key_mask may be NULL);
+ * scores/bias/probs (rows, cols) bf16, fp32 softmax, no 1/sqrt(d) scaling. */
+int fg_softmax_bias_bf16(const void* scores, const void* bias, const int* key_mask, void* probs,
+                         int64_t rows, int64_t cols, fg_stream_t stream);
+
+/* T5FeedForward gate, :19-22,109-111: out = fc1 * (0.5*g*(1+tanh(sqrt(2/pi)*(g+0.044715*g^3)))), each tensor op of
+ * that expression rounded to bf16 as the reference's explicit GELU module does. */
+int fg_gated_gelu_bf16(const void* fc1, const void* gate, void* out, int64_t n, fg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ def import_reference():
     from diffsynth.diffusion.base_pipeline import BasePipeline
     from diffsynth.utils.lora.general import GeneralLoRALoader
     from diffsynth.core.loader.file import hash_state_dict_keys
+    from diffsynth.models import wan_video_text_encoder as ref_text
+    globals()["_REF_TEXT"] = ref_text
     return dict(pipe=ref_pipe, dit=ref_dit, vae=ref_vae, sched=FlowMatchScheduler, base=BasePipeline,
                 lora=GeneralLoRALoader, hash=hash_state_dict_keys)
 
@@ -219,6 +221,31 @@ def main():
         "inputs": "z=seeded((1,48,3,4,6),31); tiled: tile_size=(3,4) tile_stride=(2,2); encode: img=seeded((3,1,64,96),32,scale=0.5).clamp(-1,1), "
                   "vid=seeded((3,9,64,96),33,scale=0.5).clamp(-1,1)",
         "source": "diffsynth/models/wan_video_vae.py WanVideoVAE.decode/tiled_decode :1103-1152,1235-1247; VideoVAE38_.decode :1326-1351"})
+
+    # ------------------------------------------------------------------ 5b. umT5 text encoder (tiny config) + padded-row zeroing
+    tkw = synthetic.TINY_TEXT_KWARGS
+    tsd = {k_: (v_ * 3 if v_.dim() == 2 else v_) for k_, v_ in
+           synthetic.random_state_dict(synthetic.text_encoder_shapes(tkw), seed=1234).items()}
+    tenc = _REF_TEXT.WanTextEncoder(**tkw).to(torch.bfloat16).eval()
+    tenc.load_state_dict(tsd)
+    g_ids = torch.Generator("cpu").manual_seed(51)
+    ids = torch.randint(0, tkw["vocab"], (1, 24), generator=g_ids)
+    mask = torch.zeros((1, 24), dtype=torch.long); mask[:, :17] = 1
+    out = {"ids": ids, "mask": mask}
+    with torch.no_grad():
+        emb = tenc(ids, mask)
+        out["encoder_bf16"] = emb.clone()
+        for v_ in mask.gt(0).sum(dim=1).long():          # WanVideoUnit_PromptEmbedder.encode_prompt :408-411
+            emb[:, v_:] = 0
+        out["prompt_emb_bf16"] = emb
+        t32 = _REF_TEXT.WanTextEncoder(**tkw).float().eval()
+        t32.load_state_dict({k_: v_.float() for k_, v_ in tsd.items()})
+        out["encoder_f32"] = t32(ids, mask)
+    out["clean"] = torch.tensor([ord(ch) for ch in _REF_TEXT.whitespace_clean(_REF_TEXT.basic_clean("  a &amp;amp; b \n\t c  "))])
+    save("text_tiny.safetensors", out, {
+        "config": str(tkw), "weights": "synthetic.random_state_dict(text_encoder_shapes(TINY_TEXT_KWARGS), seed=1234), 2-D tensors x3",
+        "inputs": "ids=randint(0,100,(1,24)) seed 51; mask first 17 ones",
+        "source": "diffsynth/models/wan_video_text_encoder.py WanTextEncoder.forward; pipelines/wan_video.py:404-412"})
 
     # ------------------------------------------------------------------ 6. pixel / noise conventions
     base = R["base"](device="cpu", torch_dtype=torch.bfloat16)

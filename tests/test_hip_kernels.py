@@ -292,6 +292,21 @@ def test_encoder_kernels(hip):
     assert torch.equal(hip.vae_latent_from_cl(dev(_cl(h96)), dev(mean), dev(inv_std), 48).cpu().unsqueeze(0), want)
 
 
+def test_text_encoder_kernels(hip):
+    from oracle import wan_text
+    heads, L = 3, 37
+    scores, bias = seeded((heads * L, L), 120, scale=4.0), seeded((heads * L, L), 121)
+    mask = torch.zeros(L, dtype=torch.int32); mask[:29] = 1
+    b = bias.view(1, heads, L, L).clone()
+    b.masked_fill_(mask.view(1, 1, 1, -1) == 0, torch.finfo(torch.bfloat16).min)
+    want = torch.softmax((scores.view(1, heads, L, L) + b).float(), dim=-1).to(torch.bfloat16).view(heads * L, L)
+    got = hip.softmax_bias(dev(scores), dev(bias), dev(mask))
+    assert_close_bf16(got, want, 1.0, "softmax_bias", max_mismatch=0.02)
+    assert not got[:, 29:].any()
+    fc1, gate = seeded((5, 64, 8), 122), seeded((5, 64, 8), 123, scale=2.0)
+    assert_close_bf16(hip.gated_gelu(dev(fc1), dev(gate)), fc1 * wan_text.gelu_tanh_explicit(gate), 1.0, "gated gelu", max_mismatch=0.02)
+
+
 def test_tile_blend(hip):
     H, W, up, T = 5, 7, 2, 2
     F_ = 4 * T - 3

@@ -11,7 +11,7 @@ import torch
 
 from conftest import seeded
 from oracle import pipeline as opipe
-from oracle import wan_dit, wan_vae
+from oracle import wan_dit, wan_text, wan_vae
 from fairygen_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -221,3 +221,51 @@ def test_pipeline_call_end_to_end(tmp_path, tiny_vae):
     got2 = np.stack([np.array(f) for f in frames2]).astype("int32")
     want2 = opipe.video_to_uint8(vid2[0]).numpy().astype("int32")
     assert np.abs(got2 - want2).mean() <= 1.5, np.abs(got2 - want2).mean()
+
+
+def _tiny_text_encoder():
+    from fairygen_amd.wan_video_text_encoder import WanTextEncoder
+    tkw = synthetic.TINY_TEXT_KWARGS
+    sd = {k: (v * 3 if v.dim() == 2 else v) for k, v in
+          synthetic.random_state_dict(synthetic.text_encoder_shapes(tkw), seed=1234).items()}
+    enc = WanTextEncoder(**tkw)
+    enc.load_state_dict(sd)
+    return enc.to(device="cuda", dtype=torch.bfloat16).eval(), sd, tkw
+
+
+def test_text_encoder_vs_golden(golden):
+    g = golden("text_tiny.safetensors")
+    enc, sd, tkw = _tiny_text_encoder()
+    with torch.no_grad():
+        out = enc(g["ids"].cuda(), g["mask"].cuda())
+    ref32 = g["encoder_f32"]
+    err_ref = (g["encoder_bf16"].float() - ref32).abs().max().item()
+    err = (out.float().cpu() - ref32).abs().max().item()
+    assert out.shape == ref32.shape and err <= 2 * err_ref + 1e-2, (err, err_ref)
+    assert cos(out, g["encoder_bf16"]) > 0.9995
+
+
+def test_prompt_strings_through_tokenizer_and_text_encoder(tiny_dit, tiny_vae):
+    """prompt=str path: pipe.tokenizer(prompt, return_mask=True) -> umT5 -> rows >= seq_len zeroed (reference
+    pipelines/wan_video.py:404-412), with a stand-in tokenizer object of the HuggingfaceTokenizer call shape."""
+    from fairygen_amd.wan_video import WanVideoPipeline, WanVideoUnit_PromptEmbedder
+    enc, sd, tkw = _tiny_text_encoder()
+
+    class FakeTokenizer:
+        def __call__(self, text, return_mask=False, add_special_tokens=True):
+            n = min(len(text.split()), 20) + 1
+            ids = torch.zeros((1, 24), dtype=torch.long)
+            ids[0, :n] = torch.tensor([(hash(w) % 97) + 1 for w in text.split()][: n - 1] + [1])
+            mask = torch.zeros((1, 24), dtype=torch.long)
+            mask[0, :n] = 1
+            return (ids, mask) if return_mask else ids
+
+    pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+    pipe.text_encoder, pipe.tokenizer = enc, FakeTokenizer()
+    unit = WanVideoUnit_PromptEmbedder()
+    with torch.no_grad():
+        ctx = unit.process(pipe, "a pig walks towards the camera")["context"]
+    ids, mask = pipe.tokenizer("a pig walks towards the camera", return_mask=True)
+    want = wan_text.encode_prompt(sd, ids, mask, tkw["num_heads"])
+    assert ctx.shape == want.shape == (1, 24, tkw["dim"])
+    assert not ctx[:, 7:].any() and cos(ctx, want) > 0.9995

@@ -8,7 +8,7 @@ import torch
 
 from conftest import seeded
 from oracle import pipeline as opipe
-from oracle import wan_dit, wan_vae
+from oracle import wan_dit, wan_text, wan_vae
 from fairygen_amd import synthetic
 
 
@@ -101,6 +101,21 @@ def test_vae_tiny_encode(golden):
     assert torch.equal(wan_vae.vae_encode(sd, [img], True, (3, 4), (2, 2)), g["encode_image_tiled_bf16"])
     sd32 = {k: v.float() for k, v in sd.items()}
     assert torch.allclose(wan_vae.vae_encode(sd32, [img.float()]), g["encode_image_f32"], atol=1e-5, rtol=1e-5)
+
+
+def _tiny_text_sd():
+    tkw = synthetic.TINY_TEXT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.text_encoder_shapes(tkw), seed=1234)
+    return {k: (v * 3 if v.dim() == 2 else v) for k, v in sd.items()}, tkw
+
+
+def test_text_encoder_tiny(golden):
+    g = golden("text_tiny.safetensors")
+    sd, tkw = _tiny_text_sd()
+    assert torch.equal(wan_text.text_encoder(sd, g["ids"], g["mask"], tkw["num_heads"]), g["encoder_bf16"])
+    assert torch.equal(wan_text.encode_prompt(sd, g["ids"], g["mask"], tkw["num_heads"]), g["prompt_emb_bf16"])
+    sd32 = {k: v.float() for k, v in sd.items()}
+    assert torch.allclose(wan_text.text_encoder(sd32, g["ids"], g["mask"], tkw["num_heads"]), g["encoder_f32"], atol=1e-5, rtol=1e-5)
 
 
 def test_pixels_and_noise(golden):
