@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gated_gelu_kernel(const bf16* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float x = (float)g[j];
-            const float p3 = rbf(x * x * x);
+            const float p3 = rbf(rbf(x * x) * x);      // torch.pow(bf16, 3.0) = x*x*x with a bf16 rounding per multiply
             const float inner = rbf(x + rbf(0.044715f * p3));
             const float th = rbf(tanhf(rbf(0.7978845608028654f * inner)));
             const float gelu = rbf(rbf(0.5f * x) * rbf(1.0f + th));
