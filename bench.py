@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=4096)
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
+    ap.add_argument("--gelu-epilogue", type=int, default=1, help="0: separate GELU kernel after ffn.0 instead of the GEMM epilogue")
     ap.add_argument("--cfg-streams", type=int, default=-1, help="1: CFG branches on two HIP streams (experimental; default off)")
     args = ap.parse_args()
 
@@ -178,6 +179,7 @@ def main():
     from fairygen_amd import hip
     hip.load()
     pipe, cfg = build_pipeline(args, device)
+    pipe.dit.gelu_epilogue = bool(args.gelu_epilogue)
     if world > 1:
         pipe.enable_sequence_parallel()
     if args.cfg_streams >= 0:
@@ -256,6 +258,7 @@ def main():
                        "weights": "random-init bf16, reference key/shape set"},
             "roofline": roofline,
         }
+        line["config"]["gelu"] = "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel"
         if args.layers:
             line["config"]["DEBUG_num_layers"] = args.layers
         if args.skip_vae:

@@ -139,6 +139,10 @@ class WanModel(nn.Module):
         self.head = Head(dim, out_dim, self.patch_size, eps)
         self.freqs = precompute_freqs_cis_3d(dim // num_heads)
         self._rope_cache = {}
+        # True: GELU(tanh) applied to the fp32 accumulator in the hipBLASLt epilogue of ffn.0 (one pass less over the
+        # (n, ffn) tensor, -1.9 % per forward; verified to be the tanh form, tools/gelu_epilogue_check.py; <= 1 bf16 ulp
+        # from the reference's "round, then GELU" order).  False: GEMM, then fg_act_bf16 on the rounded output.
+        self.gelu_epilogue = True
 
     # ------------------------------------------------------------------ load-time hooks
     def invalidate_fused(self):
@@ -238,8 +242,11 @@ class WanModel(nn.Module):
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
             x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
             # --- ffn (reference :208-209,228)
-            y = F.linear(hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh"),
-                         blk.ffn[2].weight, blk.ffn[2].bias)
+            if self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
+                f = torch._addmm_activation(blk.ffn[0].bias, h[0], blk.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
+            else:
+                f = hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
+            y = F.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)
             if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
                 x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])
             else:
