@@ -15,6 +15,7 @@
 // with the 16-B chunk index XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128.
 // Roofline: MFMA (≈4000 FLOP/B at 704x1280).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -216,6 +217,182 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-layer variant: 256 couts x 256 pixels x 64 cin per step, 8 waves (2 x 4), 128 x 64 per wave (4 x 2 MFMA tiles).
+// At 128x128 the tile needs 64 B/clk/CU of operand traffic at full MFMA rate -- the whole vector-memory path -- and the
+// register-staged ds_write_b128 path (~79 B/clk/CU) is slower still; a 256x256 tile needs 32 B/clk and the operands go
+// global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`), bypassing VGPRs and the ds_write path.  An LDS-DMA
+// wave-instruction writes 1 KiB linearly (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk;
+// out-of-range lanes (zero padding) write zeros (probed: tools/probes/lds_dma_oob.hip).  2 stages x 64 KiB of dynamic
+// LDS, one `vmcnt(0)` + barrier per step (the simple glds structure of cdna_hip_programming.md §5).
+constexpr int kT2 = 256;                       // tile rows (couts and pixels)
+constexpr int kTile2 = kT2 * kBK * 2;          // 32 KiB per operand tile
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];      // A0 A1 B0 B1, 32 KiB each
+    char* const a_lds = smem2;
+    char* const b_lds = smem2 + 2 * kTile2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int n_ctiles = p.cout_pad / kT2;
+    const int ctile = blockIdx.x % n_ctiles;
+    const int64_t ptile = blockIdx.x / n_ctiles;
+    const int c0 = ctile * kT2;
+    const int64_t m0 = ptile * kT2;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.wp), 0, p.w_bytes, 0x00020000);
+    constexpr uint32_t kOOB = 0xF0000000u;
+
+    // ---- LDS-DMA roles: wave w, instruction i (0..3) fills tile rows 8*(4w+i) .. +7; lane -> (row_local = lane>>3,
+    // destination chunk c' = lane&7), source chunk = c' ^ swizzle(row)
+    int pt[4], py[4], px[4], src_chunk[4];
+    bool pv[4];
+    uint32_t w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        src_chunk[i] = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t m = m0 + row;
+        pv[i] = m < p.M;
+        const int64_t mm = pv[i] ? m : 0;
+        px[i] = (int)(mm % p.W);
+        py[i] = (int)((mm / p.W) % p.H);
+        pt[i] = (int)(mm / ((int64_t)p.W * p.H));
+        w_off[i] = (uint32_t)(((c0 + row) * p.cin_pad + src_chunk[i] * 8) * 2);
+    }
+    const int pad = p.downsample ? 0 : (p.ks >> 1);
+    const int sstride = p.downsample ? 2 : 1;
+    const int ksteps_per_tap = p.cin_pad / kBK;
+    const int ntaps = p.kt * p.ks * p.ks;
+    const int nsteps = ntaps * ksteps_per_tap;
+    const uint32_t w_tap_stride = (uint32_t)(p.cout_pad * p.cin_pad * 2);
+
+    int ld_dt = 0, ld_dy = 0, ld_dx = 0, ld_cs = 0;
+    uint32_t ld_wbase = 0;
+    uint32_t x_off[4];
+    auto tap_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int yy = py[i] * sstride + ld_dy - pad, xx = px[i] * sstride + ld_dx - pad;
+            const bool ok = pv[i] && yy >= 0 && yy < p.H * sstride && xx >= 0 && xx < p.W * sstride;
+            if (p.upsample) { yy >>= 1; xx >>= 1; }
+            const uint32_t off = (uint32_t)((((pt[i] + ld_dt) * p.Hin + yy) * p.Win + xx) * p.Cin + src_chunk[i] * 8) * 2u;
+            x_off[i] = ok ? off : kOOB;
+        }
+    };
+    auto issue_dma = [&](int buf) {
+        const uint32_t cs_bytes = (uint32_t)ld_cs * (kBK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dst = buf * kTile2 + 8 * (4 * wave + i) * 128;      // wave-uniform LDS byte offset of the 1 KiB piece
+            const bool cin_ok = ld_cs * kBK + src_chunk[i] * 8 < p.Cin;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)(a_lds + dst), 16, w_off[i], ld_wbase + cs_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)(b_lds + dst), 16, cin_ok ? x_off[i] : kOOB, cs_bytes, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        if (++ld_cs == ksteps_per_tap) {
+            ld_cs = 0;
+            ld_wbase += w_tap_stride;
+            if (++ld_dx == p.ks) {
+                ld_dx = 0;
+                if (++ld_dy == p.ks) { ld_dy = 0; ++ld_dt; }
+            }
+            tap_offsets();
+        }
+    };
+
+    int a_rd[4][4], b_rd[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_rd[i][ks] = lds_off(wm * 128 + i * 32 + r, 2 * ks + hh);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b_rd[i][ks] = lds_off(wn * 64 + i * 32 + r, 2 * ks + hh);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+    tap_offsets();
+    issue_dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) {      // wave-uniform
+            advance();
+            issue_dma(cur ^ 1);
+        }
+        const char* ab = a_lds + cur * kTile2;
+        const char* bb = b_lds + cur * kTile2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[4], bfg[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + a_rd[i][ks]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bfg[i] = *reinterpret_cast<const bf16x8*>(bb + b_rd[i][ks]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfg[ni], acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
+        __syncthreads();
+    }
+
+    // ---- epilogue (same fragment map as the 128x128 kernel)
+    const int cout2 = p.interleave ? p.Cout / 2 : p.Cout;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t m = m0 + wn * 64 + ni * 32 + r;
+        if (m >= p.M) continue;
+        int64_t opix = m, frame_stride = 0;
+        if (p.interleave) {
+            const int64_t hw = (int64_t)p.H * p.W;
+            const int64_t t = m / hw;
+            opix = (2 * t) * hw + (m - t * hw);
+            frame_stride = hw;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = c0 + wm * 128 + mi * 32 + 8 * g + 4 * hh;
+                if (co >= p.Cout) continue;
+                int oc = co;
+                int64_t op = opix;
+                if (p.interleave && co >= cout2) { oc = co - cout2; op = opix + frame_stride; }
+                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + co);
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = rbf(acc[mi][ni][4 * g + j] + (float)bv[j]);
+                if (p.residual != nullptr) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + op * cout2 + oc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o4[j] += (float)rv[j];
+                }
+                bf16x4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = (bf16)o4[j];
+                *reinterpret_cast<bf16x4*>(p.out + op * cout2 + oc) = w4;
+            }
+    }
+}
+
 __global__ void pack_weight_kernel(const bf16* __restrict__ w, bf16* __restrict__ packed, int Cout, int Cin, int ntaps,
                                    int cout_pad, int cin_pad) {
     const int64_t total = (int64_t)ntaps * cout_pad * cin_pad;
@@ -230,6 +407,12 @@ __global__ void pack_weight_kernel(const bf16* __restrict__ w, bf16* __restrict_
 }
 
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+// FAIRYGEN_CONV_TILE=128|256 forces a tile variant (A/B measurements); unset/0 = automatic.
+inline int conv_variant_override() {
+    static const int v = [] { const char* e = getenv("FAIRYGEN_CONV_TILE"); return e ? atoi(e) : 0; }();
+    return v;
+}
 
 }  // namespace
 
@@ -275,6 +458,18 @@ int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, con
     const int64_t w_bytes = fg_conv_packed_bytes(Cout, Cin, kt, ks, ks);
     FG_CHECK_ARG(x_bytes < 0xF0000000ll && w_bytes < 0xF0000000ll, "fg_conv3d_cl_bf16: input / weights must be < 3.75 GiB (32-bit offsets)");
     p.x_bytes = (uint32_t)x_bytes; p.w_bytes = (uint32_t)w_bytes;
+    // Tile choice: the 256x256 LDS-DMA kernel when it fills the chip (>= one workgroup per CU) and Cout is a multiple
+    // of 256; the 128x128 kernel (two workgroups per CU) for the low-resolution layers and odd channel counts.
+    const int64_t blocks256 = ((p.M + kT2 - 1) / kT2) * (p.cout_pad / kT2);
+    const int variant = conv_variant_override() ? conv_variant_override() : ((Cout % kT2 == 0 && blocks256 >= 224) ? 256 : 128);
+    if (variant == 256 && Cout % kT2 == 0) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cl_256_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile2);
+        FG_CHECK_ARG(attr == hipSuccess, "fg_conv3d_cl_bf16: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
+        FG_CHECK_ARG(blocks256 < (1ll << 31), "fg_conv3d_cl_bf16: grid too large");
+        hipLaunchKernelGGL(conv3d_cl_256_kernel, dim3((unsigned)blocks256), dim3(512), 4 * kTile2, (hipStream_t)stream, p);
+        return fg_launch_status("fg_conv3d_cl_bf16 (256x256)");
+    }
     const int64_t blocks = ((p.M + kBNp - 1) / kBNp) * (p.cout_pad / kBMc);
     FG_CHECK_ARG(blocks < (1ll << 31), "fg_conv3d_cl_bf16: grid too large");
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
