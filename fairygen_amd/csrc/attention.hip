@@ -25,6 +25,7 @@
 #include "common.h"
 #include <math.h>
 #include <queue>
+#include <type_traits>
 #include <vector>
 
 #ifndef FG_EXP
@@ -53,6 +54,30 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return r;
 }
 
+// RNE pack of two fp32 into one dword of bf16 (same rounding as the (bf16) cast), kept a single instruction so that it can
+// be placed in a chosen MFMA gap.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// Gap schedule of the 32 exponentials of a tile: 21 under the 16 QK gaps, one per gap under PV gaps 16..26.
+__host__ __device__ constexpr int exps_before(int g) { return g < 16 ? (21 * g) / 16 : (g < 27 ? 21 + (g - 16) : 32); }
+
+__device__ __forceinline__ float add_f32(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // max / sum across the lane pair (l, l^32) that shares a query row.
 __device__ __forceinline__ float pair_max(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -71,6 +96,9 @@ __device__ __forceinline__ float pair_sum(float x) {
 // partial O / running max / row sum go to the workspace and are merged by attn_combine_kernel.  Direct workgroups get
 // the low block ids (dispatched first), the small pieces fill the tail: wave quantisation (2568 workgroups on 256 CUs
 // = 10.03 rounds at N = 27 280; 336 = 1.31 rounds for a 1/8 token shard) costs a fraction of a piece instead of a round.
+#ifndef FG_ATTN_SCHED
+#define FG_ATTN_SCHED 1       // 1: hand-placed per-MFMA-gap instruction schedule (step_sched); 0: compiler-scheduled step
+#endif
 #ifndef FG_ATTN_VARIANT
 #define FG_ATTN_VARIANT 8      // 8: <8 waves, 1 q-block> (256 rows / WG); 4: <4 waves, 1 q-block> (128 rows, 2 WGs per CU)
 #endif
@@ -241,6 +269,141 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
                     if (kbase + 32 * sub + (j & 3) + 8 * (j >> 2) >= Nkv) s[qi][sub][j] = -INFINITY;
     };
 
+#if FG_ATTN_SCHED
+    static_assert(QB == 1, "the gap schedule is written for one 32-row q-block per wave");
+    // Row max of a finished score tile (raw units), combined across the lane pair.
+    auto tile_max = [&](const f32x16 (&s)[QB][2]) {
+        float mt = max3(s[0][0][0], s[0][1][0], s[0][0][1]);
+#pragma unroll
+        for (int j = 1; j < 15; ++j) mt = max3(mt, s[0][1][j], s[0][0][j + 1]);
+        return pair_max(fmaxf(mt, s[0][1][15]));
+    };
+    // Deferred rescale: keep the stale max while no row of the wave outgrew it by more than 2^kDeferLog2.
+    auto absorb_max = [&](float mt) {
+        const bool grow = (mt - m_run[0]) * scale_log2e > kDeferLog2;
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+            const float m_new = fmaxf(m_run[0], mt);
+            const float alpha = fast_exp2((m_run[0] - m_new) * scale_log2e);
+            m_run[0] = m_new;
+            l_run[0] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[0][i][j] *= alpha;
+        }
+    };
+
+    // One pipeline step for tile t, written as 32 MFMA "gaps" (16 of S^T(t+1) = K(t+1) Q^T, then 16 of O^T += V(t)^T P(t)^T)
+    // with the other work of the step dealt out between them in program order and pinned there by sched_barrier:
+    //   * exp2 / bf16 pack of tile t (its max is already folded into m_run: done at the end of the previous step):
+    //     21 of the 32 exponentials under the QK gaps, 11 under the first 11 PV gaps, chunk kk complete before PV k-step kk;
+    //   * K fragment reads 3 gaps ahead of their MFMA, V^T fragment reads 2 gaps ahead;
+    //   * the row max of tile t+1 (scores complete after gap 15) under PV gaps 18..31; rescale check after the last gap;
+    //   * the LDS writes of K(t+2) / V(t+1) (global loads issued at the top of the step) in the last 4 gaps.
+    // kTail: the next tile is ragged or absent (last steps of a range): mask it, or skip its max, outside the gap stream.
+    auto step_sched = [&](f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2], int t, auto tail_tag) {
+        constexpr bool kTail = decltype(tail_tag)::value;
+        const int cur = (t - t_begin) & 1;
+        const char* kb = k_lds + (cur ^ 1) * kTileBytes;
+        const char* vb = v_lds + cur * kTileBytes;
+        load_k(t + 2);
+        load_v(t + 1);
+        const float mb = m_run[0] * scale_log2e;
+        float ps0 = 0.f, ps1 = 0.f, mt = 0.f;
+        float pe[32];
+        union PF { uint32_t w[4]; bf16x8 f; } pf[4];
+        bf16x8 ka[16];
+        union VF { s16x4 h2[2]; bf16x8 f; } va[16];
+        auto read_k = [&](int g) { ka[g] = *reinterpret_cast<const bf16x8*>(kb + k_rd[g & 7] + (g >> 3) * 8192); };
+        auto read_v = [&](int p) {
+            va[p].h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + v_rd0 + 4096 * (p >> 2) + 512 * (p & 3)));
+            va[p].h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + v_rd1 + 4096 * (p >> 2) + 512 * (p & 3)));
+        };
+        // exponential e (0..31) = element (sub = e >> 4, j = e & 15); pair unit u = e >> 1 -> word (u & 3) of pf[u >> 2]
+        auto do_exp = [&](int e) {
+            const float p = fast_exp2(sc[0][e >> 4][e & 15] * scale_log2e - mb);
+            pe[e] = p;
+        };
+        // Row-sum add as opaque asm (no SLP packing / sinking to the end of the step).  Issued one gap AFTER the exponential:
+        // gfx950 needs a wait state between a transcendental and a VALU reader of its result, and the compiler's hazard
+        // pass does not look inside inline asm.
+        auto do_add = [&](int e) { if (e & 1) ps1 = add_f32(ps1, pe[e]); else ps0 = add_f32(ps0, pe[e]); };
+        auto do_pack = [&](int u) { pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]); };
+
+        read_k(0); read_k(1); read_k(2);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 32>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            // exponentials issued before gap g: exps_before(g); this gap issues [e0, e1)
+            constexpr int e0 = exps_before(g), e1 = exps_before(g + 1), ep = g == 0 ? 0 : exps_before(g - 1);
+            if constexpr (g < 16) {
+                constexpr int sub = g >> 3, ks = g & 7;
+                if constexpr (ks == 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sn[0][sub][j] = 0.f;
+                }
+                sn[0][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[g], qf[0][ks], sn[0][sub], 0, 0, 0);
+                if constexpr (g + 3 < 16) read_k(g + 3);
+            } else {
+                constexpr int p = g - 16;
+                o[0][p & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[p].f, pf[p >> 2].f, o[0][p & 3], 0, 0, 0);
+            }
+            if constexpr (g + 2 >= 16 && g + 2 < 32) read_v(g + 2 - 16);
+            // pack unit u in the first gap that starts with both of its exponentials issued (after this gap's MFMA: the
+            // packed word is first used by a later gap's MFMA)
+            constexpr int u0 = ep / 2, u1 = e0 / 2;
+            if constexpr (u1 > u0) do_pack(u0);
+            if constexpr (u1 > u0 + 1) do_pack(u0 + 1);
+            if constexpr (e1 > e0) do_exp(e0);
+            if constexpr (e1 > e0 + 1) do_exp(e0 + 1);
+            if constexpr (e0 > ep) do_add(ep);
+            if constexpr (e0 > ep + 1) do_add(ep + 1);
+            if constexpr (!kTail && g >= 17) {      // 15 max3 steps in gaps 17..31 (scores of tile t+1 complete after gap 15)
+                constexpr int i = g - 17;
+                if constexpr (i == 0) mt = max3(sn[0][0][0], sn[0][1][0], sn[0][0][1]);
+                else mt = max3(mt, sn[0][1][i], sn[0][0][i + 1]);
+            }
+            if constexpr (g == 28) write_k(cur);
+            if constexpr (g == 30) write_v(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        l_run[0] += ps0 + ps1;
+        if (!kTail) {
+            absorb_max(pair_max(fmaxf(mt, sn[0][1][15])));
+        } else if (t + 1 < t_end) {
+            if ((int64_t)(t + 2) * kBN > Nkv) mask_tile(sn, t + 1);      // ragged last tile (wave-uniform)
+            absorb_max(tile_max(sn));
+        }
+        __syncthreads();
+    };
+
+    // ---- prologue: K(0), V(0), K(1) resident; scores(0) computed and their max taken
+    f32x16 sA[QB][2], sB[QB][2];
+    load_k(t_begin);
+    load_v(t_begin);
+    write_k(0);
+    write_v(0);
+    load_k(t_begin + 1);
+    write_k(1);
+    __syncthreads();
+    qk_tile(sA, 0);
+    if ((int64_t)(t_begin + 1) * kBN > Nkv) mask_tile(sA, t_begin);
+    m_run[0] = tile_max(sA);
+    __syncthreads();      // every wave is done with the first K tile before step 0 overwrites it
+
+    // fast steps: the next tile exists in this range and is full
+    const int t_fast = min(t_end - 1, (int)(Nkv / kBN) - 1);
+    int t = t_begin;
+    for (; t + 1 < t_fast; t += 2) {
+        step_sched(sA, sB, t, std::false_type{});
+        step_sched(sB, sA, t + 1, std::false_type{});
+    }
+    for (; t < t_end; ++t) {      // <= 3 steps: odd fast step, ragged-next step, last step
+        step_sched(sA, sB, t, std::true_type{});
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) sA[0][sub] = sB[0][sub];
+    }
+#else
     // One pipeline step for tile t: sc = scores(t) (ready), sn <- scores(t+1) while softmax(sc) runs, then PV(t).
     auto step = [&](f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2], int t) {
         const int cur = (t - t_begin) & 1;
@@ -336,6 +499,8 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
         step(sB, sA, t + 1);
     }
     if (t < t_end) step(sA, sB, t);
+
+#endif
 
     // ---- epilogue: lane holds O[query r][d = 32db + 8g + 4hh + 0..3]
 #pragma unroll

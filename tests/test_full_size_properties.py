@@ -1,0 +1,88 @@
+"""BASELINE.json full sizes (704x1280x121: N = 27 280 tokens, 24 heads; VAE layers at 480x832 tiles) on the GPU, checked
+through size-independent properties and through the CPU oracle on SAMPLED outputs (the oracle cannot finish the full
+tensors in seconds, but any output row / pixel depends on the full key set / receptive field only)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+N, H, D = 27280, 24, 128
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator("cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda", dtype=torch.float32) * scale).to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from fairygen_amd import hip as h
+    h.load()
+    return h
+
+
+def test_attention_full_size_sampled_rows_and_properties(hip):
+    q, k, v = _rand((1, N, H * D), 1), _rand((1, N, H * D), 2), _rand((1, N, H * D), 3)
+    out = hip.attention(q, k, v, H)
+    # (1) sampled query rows (first / last / block edges / ragged tail) against an fp32 softmax over ALL 27 280 keys
+    rows = torch.tensor([0, 1, 255, 256, 257, 13639, 27135, 27136, 27263, 27279], device="cuda")
+    qs = q[0, rows].view(-1, H, D).transpose(0, 1).float()                   # (H, R, D)
+    kf = k[0].view(N, H, D).transpose(0, 1).float()
+    vf = v[0].view(N, H, D).transpose(0, 1).float()
+    ref = torch.softmax(qs @ kf.transpose(1, 2) * D ** -0.5, dim=-1) @ vf      # (H, R, D)
+    got = out[0, rows].view(-1, H, D).transpose(0, 1).float()
+    assert (got - ref).abs().max().item() < 6e-3, (got - ref).abs().max().item()
+    # (2) rows of softmax sum to one: constant V comes back unchanged (up to bf16 rounding of P)
+    vc = torch.full_like(v, 0.75)
+    oc = hip.attention(q, k, vc, H).float()
+    assert (oc - 0.75).abs().max().item() < 4e-3
+    # (3) permuting the keys (with their values) does not change the result beyond summation order
+    perm = torch.randperm(N, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    op = hip.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous(), H).float()
+    assert (op - out.float()).abs().max().item() < 4e-3
+    # (4) a token shard (1/8 of the queries, the split-every-q-block decomposition) equals the same rows of the full call
+    lo, hi = 3 * 3410, 4 * 3410
+    os_ = hip.attention(q[:, lo:hi].contiguous(), k, v, H).float()
+    assert (os_ - out[:, lo:hi].float()).abs().max().item() < 4e-3
+
+
+@pytest.mark.parametrize("cin,cout,T,Hh,Ww", [(256, 256, 4, 240, 416), (1024, 1024, 2, 60, 104)])
+def test_conv_full_size_sampled_pixels(hip, cin, cout, T, Hh, Ww):
+    """A last-stage and a second-stage decoder layer of a 480x832 tile (256x256 LDS-DMA tile variant), checked on sampled
+    output pixels against F.conv3d over their receptive fields, plus linearity in the input."""
+    x = _rand((T + 2, Hh, Ww, cin), 5)
+    w = _rand((cout, cin, 3, 3, 3), 6, scale=(cin * 27) ** -0.5)
+    b = _rand((cout,), 7, scale=0.1)
+    wp = hip.conv_pack_weight(w)
+    y = hip.conv3d_cl(x, wp, b, cout, 3, 3)
+    assert y.shape == (T, Hh, Ww, cout)
+    xp = F.pad(x.float().permute(3, 0, 1, 2).unsqueeze(0), (1, 1, 1, 1, 0, 0))        # (1,C,T+2,H+2,W+2), zero spatial pad
+    for (t, yy, xx) in [(0, 0, 0), (T - 1, Hh - 1, Ww - 1), (1, 17, 255 % Ww), (T - 1, Hh // 2, 0), (0, Hh - 1, Ww // 3)]:
+        patch = xp[:, :, t:t + 3, yy:yy + 3, xx:xx + 3]
+        ref = F.conv3d(patch, w.float(), b.float())[0, :, 0, 0, 0]
+        assert (y[t, yy, xx].float() - ref).abs().max().item() < 3e-2
+    y2 = hip.conv3d_cl((x.float() * 0.5).to(torch.bfloat16), wp, torch.zeros_like(b), cout, 3, 3).float()
+    y1 = hip.conv3d_cl(x, wp, torch.zeros_like(b), cout, 3, 3).float()
+    assert (y2 - 0.5 * y1).abs().max().item() < 3e-2
+
+
+def test_token_kernels_full_size_statistics(hip):
+    """LN+modulate / RMSNorm+RoPE on the full (27 280, 3072) token tensor: row statistics and norm preservation."""
+    from fairygen_amd.wan_video_dit import precompute_freqs_cis_3d
+    x = _rand((1, N, 3072), 8, scale=2.0)
+    mod = hip.ModTable(torch.zeros((2, 6, 3072), dtype=torch.bfloat16, device="cuda"), 880)
+    y = hip.ln_modulate(x, mod, 0, 1, 1e-6).float()                                   # zero shift/scale: plain LayerNorm
+    assert y.mean(-1).abs().max().item() < 2e-2 and (y.var(-1, unbiased=False) - 1).abs().max().item() < 2e-2
+    f, h, w = 31, 22, 40
+    fr = precompute_freqs_cis_3d(128)
+    tab = torch.cat([fr[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                     fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(N, -1)
+    ones = torch.ones(3072, dtype=torch.bfloat16, device="cuda")
+    r0 = hip.rmsnorm_rope(x, ones, 24, 1e-6).float()
+    r1 = hip.rmsnorm_rope(x, ones, 24, 1e-6, tab.real.contiguous().cuda(), tab.imag.contiguous().cuda()).float()
+    assert (r0.pow(2).mean(-1) - 1).abs().max().item() < 2e-2                         # unit RMS
+    n0 = r0.view(N, 24, 64, 2).pow(2).sum(-1)
+    n1 = r1.view(N, 24, 64, 2).pow(2).sum(-1)
+    assert bool(((n0 - n1).abs() <= 0.02 * n0 + 0.01).all())                           # rotations preserve each pair's norm
+    assert torch.equal(r0[0, :1], r1[0, :1])                                           # token (0,0,0): angle 0 -> identity
