@@ -69,8 +69,20 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
-// Gap schedule of the 32 exponentials of a tile: 21 under the 16 QK gaps, one per gap under PV gaps 16..26.
-__host__ __device__ constexpr int exps_before(int g) { return g < 16 ? (21 * g) / 16 : (g < 27 ? 21 + (g - 16) : 32); }
+#ifndef FG_EXP_QK
+#define FG_EXP_QK 21      // exponentials placed under the 16 QK gaps (the rest: one per PV gap from gap 16)
+#endif
+#ifndef FG_KDIST
+#define FG_KDIST 3        // K fragment ds_read issued this many gaps before its MFMA
+#endif
+#ifndef FG_VDIST
+#define FG_VDIST 2        // V^T fragment reads issued this many gaps before their MFMA
+#endif
+// Gap schedule of the 32 exponentials of a tile: FG_EXP_QK under the 16 QK gaps, then one per PV gap.
+__host__ __device__ constexpr int exps_before(int g) {
+    return g < 16 ? (FG_EXP_QK * g) / 16 : (FG_EXP_QK + (g - 16) < 32 ? FG_EXP_QK + (g - 16) : 32);
+}
+static_assert(exps_before(27) == 32, "the last exponential must be issued by gap 26 (its pack feeds the MFMA of gap 28)");
 
 __device__ __forceinline__ float add_f32(float a, float b) {
     float r;
@@ -182,7 +194,8 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
         st_v[i] = v_lds_off(st_row + ST_ROWS * i, st_chunk);
     }
     // Buffer descriptors (wave-uniform) bound the loads to the head's rows: rows >= Nkv (ragged last tile, prefetch
-    // past the end) come back as zeros from the hardware range check -- no clamps, 32-bit offsets.
+    // past the end) come back as zeros from the hardware range check -- no clamps, 32-bit offsets.  The tile base stays in
+    // the VGPR offset: the range check covers voffset + inst_offset only, not the scalar soffset.
     const uint32_t k_bytes = (uint32_t)((Nkv - 1) * ldk * 2 + kD * 2), v_bytes = (uint32_t)((Nkv - 1) * ldv * 2 + kD * 2);
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(kp), 0, k_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(vp), 0, v_bytes, 0x00020000);
@@ -297,13 +310,16 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
     // with the other work of the step dealt out between them in program order and pinned there by sched_barrier:
     //   * exp2 / bf16 pack of tile t (its max is already folded into m_run: done at the end of the previous step):
     //     21 of the 32 exponentials under the QK gaps, 11 under the first 11 PV gaps, chunk kk complete before PV k-step kk;
-    //   * K fragment reads 3 gaps ahead of their MFMA, V^T fragment reads 2 gaps ahead;
+    //   * K fragment reads FG_KDIST gaps ahead of their MFMA, V^T fragment reads FG_VDIST gaps ahead;
     //   * the row max of tile t+1 (scores complete after gap 15) under PV gaps 18..31; rescale check after the last gap;
     //   * the LDS writes of K(t+2) / V(t+1) (global loads issued at the top of the step) in the last 4 gaps.
     // kTail: the next tile is ragged or absent (last steps of a range): mask it, or skip its max, outside the gap stream.
-    auto step_sched = [&](f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2], int t, auto tail_tag) {
+    // cur_tag: the K/V ring parity as a compile-time constant (0 / 1: every LDS address is a loop-invariant per-lane base plus
+    // an immediate) or -1 (runtime parity, tail steps).
+    auto step_sched = [&](f32x16 (&sc)[QB][2], f32x16 (&sn)[QB][2], int t, auto tail_tag, auto cur_tag) {
         constexpr bool kTail = decltype(tail_tag)::value;
-        const int cur = (t - t_begin) & 1;
+        constexpr int kCur = decltype(cur_tag)::value;
+        const int cur = kCur >= 0 ? kCur : ((t - t_begin) & 1);
         const char* kb = k_lds + (cur ^ 1) * kTileBytes;
         const char* vb = v_lds + cur * kTileBytes;
         load_k(t + 2);
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
         auto do_add = [&](int e) { if (e & 1) ps1 = add_f32(ps1, pe[e]); else ps0 = add_f32(ps0, pe[e]); };
         auto do_pack = [&](int u) { pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]); };
 
-        read_k(0); read_k(1); read_k(2);
+        static_for<0, FG_KDIST>([&](auto i) { read_k(decltype(i)::value); });
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 32>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -343,12 +359,12 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
                     for (int j = 0; j < 16; ++j) sn[0][sub][j] = 0.f;
                 }
                 sn[0][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[g], qf[0][ks], sn[0][sub], 0, 0, 0);
-                if constexpr (g + 3 < 16) read_k(g + 3);
+                if constexpr (g + FG_KDIST < 16) read_k(g + FG_KDIST);
             } else {
                 constexpr int p = g - 16;
                 o[0][p & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[p].f, pf[p >> 2].f, o[0][p & 3], 0, 0, 0);
             }
-            if constexpr (g + 2 >= 16 && g + 2 < 32) read_v(g + 2 - 16);
+            if constexpr (g + FG_VDIST >= 16 && g + FG_VDIST < 32) read_v(g + FG_VDIST - 16);
             // pack unit u in the first gap that starts with both of its exponentials issued (after this gap's MFMA: the
             // packed word is first used by a later gap's MFMA)
             constexpr int u0 = ep / 2, u1 = e0 / 2;
@@ -395,11 +411,11 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
     const int t_fast = min(t_end - 1, (int)(Nkv / kBN) - 1);
     int t = t_begin;
     for (; t + 1 < t_fast; t += 2) {
-        step_sched(sA, sB, t, std::false_type{});
-        step_sched(sB, sA, t + 1, std::false_type{});
+        step_sched(sA, sB, t, std::false_type{}, std::integral_constant<int, 0>{});
+        step_sched(sB, sA, t + 1, std::false_type{}, std::integral_constant<int, 1>{});
     }
     for (; t < t_end; ++t) {      // <= 3 steps: odd fast step, ragged-next step, last step
-        step_sched(sA, sB, t, std::true_type{});
+        step_sched(sA, sB, t, std::true_type{}, std::integral_constant<int, -1>{});
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) sA[0][sub] = sB[0][sub];
     }
