@@ -9,8 +9,11 @@ forward(+), forward(-), CFG combine + Euler update, first-frame re-pin.  The tim
 num_inference_steps = K: K steps followed by the VAE decode to (1,3,121,704,1280) (tiled exactly like
 inference.py's tiled=True unless --untiled), inputs resident in HBM; value = frames / t_clip.  Default K = 50
 is the headline configuration; ms_per_step = t_clip / K (decode amortised).
-N > 1 ("strong" scaling: one clip, total work fixed): tokens sharded by latent-temporal ranges with an RCCL
-K/V all-gather per self-attention layer; VAE tiles are decoded round-robin over ranks.
+N > 1 ("strong" scaling: one clip, total work fixed): world = cfg_parallel x sp (fairygen_amd/sequence_parallel.py):
+tokens sharded by latent-temporal ranges inside a sequence-parallel group with either an RCCL K/V all-gather or the
+Ulysses all-to-all pair around every self-attention, optionally one CFG branch per half of the ranks; VAE tiles
+are dealt over all ranks.  --layout auto (default) times one denoise step of every candidate layout during the
+untimed warm-up and keeps the fastest (env FAIRYGEN_PARALLEL=cfg2-ulysses etc. forces one).
 """
 import argparse
 import json
@@ -103,6 +106,25 @@ class KernelTimer:
                 "traffic": PMC_HBM_BYTES_PER_LAUNCH.get(shape)}
 
 
+LAYOUTS = ("cfg1-allgather", "cfg1-ulysses", "cfg2-allgather", "cfg2-ulysses")
+
+
+def candidate_layouts(world, num_heads):
+    """(cfg_parallel, attn_mode) candidates for a world size; the attention exchange is moot when sp == 1."""
+    out = []
+    for cfgp in (2, 1):
+        if world % cfgp:
+            continue
+        sp = world // cfgp
+        if sp == 1:
+            out.append((cfgp, "allgather"))
+            continue
+        if num_heads % sp == 0:
+            out.append((cfgp, "ulysses"))
+        out.append((cfgp, "allgather"))
+    return out
+
+
 def cpu_baseline(args, n_tokens, frames, steps):
     """The CPU oracle ("port" of the reference's PyTorch path, pinned bit-exact to it by tests/golden) timed on the
     host cores on a bounded sample, extrapolated to the clip: one full-width DiT block at Ns tokens (GEMM part scaled
@@ -160,6 +182,8 @@ def main():
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
     ap.add_argument("--gelu-epilogue", type=int, default=1, help="0: separate GELU kernel after ffn.0 instead of the GEMM epilogue")
     ap.add_argument("--cfg-streams", type=int, default=-1, help="1: CFG branches on two HIP streams (experimental; default off)")
+    ap.add_argument("--layout", default=os.environ.get("FAIRYGEN_PARALLEL", "auto"), choices=("auto",) + LAYOUTS,
+                    help="N>1: how the ranks are used (auto: time every candidate for one step in the warm-up, keep the fastest)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,18 +194,16 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("FAIRYGEN_BENCH_BACKEND", "nccl")      # "gloo": rehearsal with several ranks on one GPU
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(device))
-        else:
-            dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fairygen_amd import hip
     hip.load()
     pipe, cfg = build_pipeline(args, device)
     pipe.dit.gelu_epilogue = bool(args.gelu_epilogue)
-    if world > 1:
-        pipe.enable_sequence_parallel()
+    if world > 1 and args.layout != "auto":
+        cfgp, mode = args.layout.split("-")
+        pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
     if args.cfg_streams >= 0:
         pipe.cfg_streams = bool(args.cfg_streams)
     H, W, F_ = args.height, args.width, args.frames
@@ -206,15 +228,39 @@ def main():
         video = pipe.decode_latents(latents, tiled=not args.untiled)
         return latents, video
 
+    def sync_max(t):
+        if world == 1:
+            return t
+        tt = torch.tensor([t], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.item()
+
     phase = {}
+    autotune = None
     with torch.no_grad():
+        if world > 1 and args.layout == "auto":
+            # untimed: one warm step + one timed step of every candidate layout at full shape; all ranks agree on the
+            # fastest through a MAX all-reduce of their times
+            autotune = {}
+            for cfgp, mode in candidate_layouts(world, cfg["num_heads"]):
+                pipe.enable_sequence_parallel(cfg_parallel=cfgp, attn_mode=mode)
+                run_clip(1, decode=False)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                run_clip(1, decode=False)
+                torch.cuda.synchronize()
+                autotune[f"cfg{cfgp}-{mode}"] = round(sync_max(time.perf_counter() - t0) * 1e3, 2)
+            best = min(autotune, key=autotune.get)
+            cfgp, mode = best.split("-")
+            pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
         # warmup: W denoise steps at full shape + a small decode (packs the VAE weights, warms the allocator)
         if args.warmup > 0:
             run_clip(args.warmup, decode=False)
         if not args.skip_vae:
             pipe.vae.decode(noise[:, :, :2, :8, :8].contiguous(), device=device, tiled=False)
             if world > 1:      # first-use set-up of the tile broadcast stays out of the timed region
-                pipe.sequence_shard.broadcast(torch.zeros(1024, dtype=torch.bfloat16, device=device), src=0)
+                pipe.parallel.world.broadcast(torch.zeros(1024, dtype=torch.bfloat16, device=device), src=0)
         torch.cuda.synchronize()
         timer = KernelTimer()
         timer.install()
@@ -230,10 +276,7 @@ def main():
         torch.cuda.synchronize()
         t_clip = time.perf_counter() - t0
         timer.uninstall()
-    if world > 1:
-        tt = torch.tensor([t_clip], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_clip = tt.item()
+    t_clip = sync_max(t_clip)
 
     if rank == 0:
         st = timer.self_attention_stats()
@@ -254,11 +297,13 @@ def main():
                        "sec_per_clip": round(t_clip, 2), "denoise_s": round(phase.get("denoise_s", t_clip), 2),
                        "vae_decode_s": round(t_clip - phase.get("denoise_s", t_clip), 2), "tokens": n_tokens, "num_inference_steps": args.steps,
                        "lora": "rank-32 merged, fused at load" if not args.no_lora else "none",
-                       "parallelism": f"sp{world}" if world > 1 else "single",
+                       "parallelism": pipe.parallel.describe() if world > 1 else "single",
                        "weights": "random-init bf16, reference key/shape set"},
             "roofline": roofline,
         }
         line["config"]["gelu"] = "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel"
+        if autotune is not None:
+            line["config"]["layout_autotune_ms_per_step"] = autotune
         if args.layers:
             line["config"]["DEBUG_num_layers"] = args.layers
         if args.skip_vae:

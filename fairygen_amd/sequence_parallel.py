@@ -3,20 +3,39 @@
 Specification = the reference's USP path (``utils/xfuser/xdit_context_parallel.py:57-146`` and
 ``pipelines/wan_video.py:1224-1227,1310-1315,1379-1382``): tokens are frame-major, so a contiguous token
 range IS a latent-temporal shard; every rank runs all 30 blocks on its N/P tokens, everything except
-self-attention is token-local, and the head output is all-gathered at the end.  Instead of xfuser's four
-Ulysses all-to-alls per layer we all-gather K and V (after RMSNorm+RoPE) once per layer: Wan's attention is
-full 3-D, so the exact "halo" of a temporal shard is the whole sequence.  On the fully
-connected xGMI mesh each peer's 42 MB (N=27 280, P=8) crosses its own link.
+self-attention is token-local, and the head output is all-gathered at the end.  Wan's attention is full 3-D, so
+the exact "halo" of a temporal shard is the whole sequence; two exact exchanges are built:
 
-One process per GPU; the process group is torch.distributed's ("nccl" == RCCL on ROCm; "gloo" in CPU tests).
+* ``attn_mode="allgather"``: K and V (after RMSNorm+RoPE) are all-gathered once per layer (2 collectives, 7/8 of
+  2·N·3072·2 B received per rank: 293 MB at N = 27 280, P = 8); attention = local queries x all keys, all heads.
+* ``attn_mode="ulysses"`` (what xfuser does, :125-146): one all-to-all turns the token shard of q/k/v into a
+  head shard (all N tokens, 24/P heads), attention runs per head group over the whole sequence, a second
+  all-to-all brings the output back (2 collectives, 4·(N/P)·3072·2 B·(P-1)/P sent per rank: 73 MB at P = 8 —
+  a quarter of the all-gather traffic, and on the fully connected xGMI mesh every peer pair uses its own link).
+
+On top of either, the two CFG branches of a denoise step are independent until the combine
+(``pipelines/wan_video.py:296-301``), so ``ParallelLayout(cfg_parallel=2)`` gives each half of the ranks one
+branch (sequence-parallel inside the half) and exchanges the two predictions with ONE world all-gather per step.
+
+One process per GPU; process groups are torch.distributed's ("nccl" == RCCL on ROCm; "gloo" in CPU tests and in
+the several-ranks-on-one-GPU rehearsal, where device tensors are staged through the host).
 """
 import torch
 import torch.distributed as dist
 
+ATTN_MODES = ("allgather", "ulysses")
+
+
+def _staged(t, group):
+    """True when `t` lives on the device but the group's backend has no device collectives (gloo rehearsal)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
 
 class TokenShard:
-    def __init__(self, group=None):
-        self.group = group
+    def __init__(self, group=None, attn_mode="allgather"):
+        if attn_mode not in ATTN_MODES:
+            raise ValueError(f"attn_mode must be one of {ATTN_MODES}, got {attn_mode!r}")
+        self.group, self.attn_mode = group, attn_mode
         if dist.is_available() and dist.is_initialized():
             self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
@@ -32,17 +51,19 @@ class TokenShard:
         lo = min(rank * size, n)
         return lo, min(lo + size, n)
 
-    def _gather_rows(self, local, size):
-        """local (rows<=size, C) -> (world*size, C); short ranks are zero padded (only a suffix is padding)."""
-        c = local.shape[-1]
+    def _padded(self, local, size):
+        """(rows<=size, C) -> contiguous (size, C); short ranks are zero padded (only a suffix is padding)."""
         if local.shape[0] == size and local.is_contiguous():
-            buf = local
-        else:
-            buf = torch.zeros((size, c), dtype=local.dtype, device=local.device)
-            buf[: local.shape[0]].copy_(local)
-        full = torch.empty((self.world_size * size, c), dtype=local.dtype, device=local.device)
-        if local.is_cuda and dist.get_backend(self.group) == "gloo":
-            # backend without device-tensor collectives (single-GPU rehearsal): stage through the host
+            return local
+        buf = torch.zeros((size, local.shape[-1]), dtype=local.dtype, device=local.device)
+        buf[: local.shape[0]].copy_(local)
+        return buf
+
+    def _gather_rows(self, local, size):
+        """local (rows<=size, C) -> (world*size, C)."""
+        buf = self._padded(local, size)
+        full = torch.empty((self.world_size * size, local.shape[-1]), dtype=local.dtype, device=local.device)
+        if _staged(local, self.group):
             host = torch.empty(full.shape, dtype=full.dtype)
             dist.all_gather_into_tensor(host, buf.cpu(), group=self.group)
             full.copy_(host)
@@ -50,6 +71,7 @@ class TokenShard:
             dist.all_gather_into_tensor(full, buf, group=self.group)
         return full
 
+    # ------------------------------------------------------------------ K/V all-gather exchange
     def all_gather_kv(self, k, v, n=None):
         """k, v (1, n_local, C) of this rank's tokens -> (1, N, C) of all tokens, in token order."""
         if self.world_size == 1:
@@ -76,11 +98,35 @@ class TokenShard:
             return x
         return self._gather_rows(x[0], self.chunk(n))[:n].unsqueeze(0).contiguous()
 
+    # ------------------------------------------------------------------ Ulysses (head <-> token) exchange
+    def heads_local(self, num_heads):
+        if num_heads % self.world_size != 0:
+            raise ValueError(f"attn_mode='ulysses' needs num_heads ({num_heads}) divisible by the group size "
+                             f"({self.world_size}); use attn_mode='allgather'")
+        return num_heads // self.world_size
+
+    def ulysses_qkv_async(self, q, k, v, n, num_heads):
+        """q, k, v (1, n_local, H*D) of this rank's tokens (v may be a column slice of a wider buffer).  Starts ONE
+        all-to-all; `.wait()` -> (q, k, v) as (1, N, (H/P)*D) views (row stride 3*(H/P)*D) of ALL tokens for this
+        rank's head group [rank*H/P, (rank+1)*H/P)."""
+        return _PendingQKV(self, q, k, v, n, num_heads)
+
+    def ulysses_out_buffer(self, n, cols, like):
+        """(P*chunk, cols) buffer for the head-group attention output: the kernel writes rows [0, N), the reverse
+        all-to-all sends equal row blocks (rows >= N are padding of the trailing ranks)."""
+        return torch.empty((self.world_size * self.chunk(n), cols), dtype=like.dtype, device=like.device)
+
+    def ulysses_out_async(self, o_full, n, n_local):
+        """o_full (P*chunk, (H/P)*D): this rank's head group for all tokens (rows >= N ignored).  Starts the reverse
+        all-to-all; `.wait()` -> (1, n_local, H*D) for this rank's tokens, all heads."""
+        return _PendingOut(self, o_full, n, n_local)
+
+    # ------------------------------------------------------------------ VAE tiles
     def broadcast(self, tensor, src):
-        """In-place broadcast from group rank `src` (VAE tiles decoded round-robin over ranks)."""
+        """In-place broadcast from group rank `src` (VAE tiles decoded by different ranks)."""
         if self.world_size > 1:
             gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
-            if tensor.is_cuda and dist.get_backend(self.group) == "gloo":
+            if _staged(tensor, self.group):
                 host = tensor.cpu()
                 dist.broadcast(host, src=gsrc, group=self.group)
                 tensor.copy_(host)
@@ -96,17 +142,12 @@ class _PendingKV:
             self.kf, self.vf = k[0], v[0]
             return
         size = shard.chunk(n)
-        staged = k.is_cuda and dist.get_backend(shard.group) == "gloo"
-        if staged:      # single-GPU rehearsal backend: synchronous, through the host
+        if _staged(k, shard.group):      # single-GPU rehearsal backend: synchronous, through the host
             self.kf, self.vf = shard._gather_rows(k[0], size), shard._gather_rows(v[0], size)
             return
         bufs = []
         for t in (k[0], v[0]):
-            if t.shape[0] == size and t.is_contiguous():
-                buf = t
-            else:
-                buf = torch.zeros((size, t.shape[-1]), dtype=t.dtype, device=t.device)
-                buf[: t.shape[0]].copy_(t)
+            buf = shard._padded(t, size)
             full = torch.empty((shard.world_size * size, t.shape[-1]), dtype=t.dtype, device=t.device)
             self.works.append(dist.all_gather_into_tensor(full, buf, group=shard.group, async_op=True))
             bufs.append((full, buf))
@@ -117,3 +158,119 @@ class _PendingKV:
         for w in self.works:
             w.wait()
         return self.kf[: self.n].unsqueeze(0), self.vf[: self.n].unsqueeze(0)
+
+
+def _all_to_all_rows(shard, send, recv):
+    """Equal-split all-to-all over dim 0; returns the async work (None when it already completed)."""
+    if _staged(send, shard.group):
+        hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(hr, hs, group=shard.group)
+        recv.copy_(hr)
+        return None
+    return dist.all_to_all_single(recv, send, group=shard.group, async_op=True)
+
+
+class _PendingQKV:
+    """Send layout (P, chunk, 3, g): block p = head group p of my tokens, per token [q_g | k_g | v_g] (g = H/P*D
+    columns).  Receive layout (P, chunk, 3, g) = (P*chunk tokens in global order, 3g): q / k / v of my head group
+    are column slices with row stride 3g — the attention kernel takes leading dimensions, so nothing is repacked."""
+
+    def __init__(self, shard, q, k, v, n, num_heads):
+        p, size = shard.world_size, shard.chunk(n)
+        hl = shard.heads_local(num_heads)
+        c = q.shape[-1]
+        g = c // num_heads * hl
+        n_loc = q.shape[1]
+        self.n, self.g = n, g
+        send = torch.empty((p, size, 3, g), dtype=q.dtype, device=q.device)
+        if n_loc < size:
+            send[:, n_loc:].zero_()
+        for j, t in enumerate((q, k, v)):
+            send[:, :n_loc, j].copy_(t[0].unflatten(-1, (p, g)).transpose(0, 1))
+        self.recv = torch.empty((p * size, 3 * g), dtype=q.dtype, device=q.device)
+        self._send = send
+        self.work = _all_to_all_rows(shard, send.view(p * size, 3 * g), self.recv)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        r, g = self.recv[: self.n].unsqueeze(0), self.g
+        return r[..., :g], r[..., g:2 * g], r[..., 2 * g:]
+
+
+class _PendingOut:
+    def __init__(self, shard, o_full, n, n_local):
+        p, size = shard.world_size, shard.chunk(n)
+        assert o_full.shape[0] == p * size and o_full.is_contiguous()
+        self.p, self.size, self.n_local = p, size, n_local
+        self._send = o_full
+        self.recv = torch.empty_like(o_full)
+        self.work = _all_to_all_rows(shard, o_full, self.recv)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        g = self.recv.shape[-1]
+        blocks = self.recv.view(self.p, self.size, g)[:, : self.n_local]          # (head group, token, g)
+        return blocks.transpose(0, 1).reshape(1, self.n_local, self.p * g)         # one copy: (token, all heads)
+
+
+# ---------------------------------------------------------------------------------------------- rank layout
+_subgroups = {}
+
+
+def _subgroup(ranks):
+    """Process group over `ranks` (global ranks), created once per rank set; every process must call this for every
+    set in the same order (torch.distributed.new_group contract)."""
+    key = tuple(ranks)
+    if key not in _subgroups:
+        _subgroups[key] = dist.new_group(list(ranks))
+    return _subgroups[key]
+
+
+class ParallelLayout:
+    """world = cfg_parallel x sp.  cfg_parallel = 1: every rank runs both CFG branches on its token shard of the
+    whole world.  cfg_parallel = 2: ranks [0, W/2) run the positive branch, [W/2, W) the negative one, each half
+    sequence-parallel over its own group; one world all-gather per step exchanges the predictions."""
+
+    def __init__(self, cfg_parallel=1, attn_mode="allgather"):
+        self.world = TokenShard(None, attn_mode)
+        w = self.world.world_size
+        if cfg_parallel not in (1, 2) or w % cfg_parallel != 0:
+            raise ValueError(f"cfg_parallel must be 1 or 2 and divide the world size {w}, got {cfg_parallel}")
+        self.cfg_parallel, self.attn_mode = cfg_parallel, attn_mode
+        if cfg_parallel == 1 or w == 1:
+            self.cfg_parallel, self.branch, self.shard = 1, None, self.world
+        else:
+            sp = w // 2
+            groups = [_subgroup(range(b * sp, (b + 1) * sp)) for b in range(2)]      # both created on every rank
+            self.branch = self.world.rank // sp
+            self.shard = TokenShard(groups[self.branch], attn_mode)
+
+    @property
+    def sp(self):
+        return self.shard.world_size
+
+    def describe(self):
+        tag = f"cfg{self.cfg_parallel}xsp{self.sp}"
+        return tag + (f"-{self.attn_mode}" if self.sp > 1 else "")
+
+    def gather_branches(self, out_local, n):
+        """out_local (1, n_local, C): this rank's token shard of ITS branch's prediction -> (2, N, C): the positive
+        and the negative prediction over all tokens, on every rank (one world all-gather)."""
+        assert self.cfg_parallel == 2
+        size = self.shard.chunk(n)
+        full = self.world._gather_rows(out_local[0], size)                      # (2*sp*size, C), branch-major
+        return full.view(2, self.sp * size, -1)[:, :n]
+
+
+def assign_tiles(costs, world):
+    """VAE tile -> rank: longest-processing-time-first list scheduling (deterministic, same on every rank).
+    Returns owner[i] for tile i.  6 tiles of unequal area at 704x1280 on 4 ranks: max load 2348 latent pixels
+    instead of 3068 for round-robin."""
+    load, owner = [0] * world, [0] * len(costs)
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner

@@ -165,7 +165,8 @@ class WanVideoPipeline(torch.nn.Module):
         ]
         self.post_units = []
         self.model_fn = model_fn_wan_video
-        self.sequence_shard = None          # set by enable_sequence_parallel()
+        self.sequence_shard = None          # set by enable_sequence_parallel(): token shard group of this rank
+        self.parallel = None                # sequence_parallel.ParallelLayout (world = cfg_parallel x sp)
         self.cfg_streams = False            # True: issue the two CFG branches on two HIP streams (experimental)
         self._cfg_side_streams = None
         self.use_unified_sequence_parallel = False
@@ -204,12 +205,21 @@ class WanVideoPipeline(torch.nn.Module):
 
     def enable_usp(self):
         """The reference's use_usp=True monkey-patches xfuser Ulysses attention (:84-95); here the same switch
-        turns on latent-temporal token sharding with an RCCL K/V all-gather (sequence_parallel.py)."""
-        return self.enable_sequence_parallel()
+        turns on latent-temporal token sharding over RCCL with the same Ulysses exchange (sequence_parallel.py)."""
+        return self.enable_sequence_parallel(attn_mode="ulysses" if self.dit is None or self._ulysses_ok() else "allgather")
 
-    def enable_sequence_parallel(self, group=None):
-        from .sequence_parallel import TokenShard
-        self.sequence_shard = TokenShard(group)
+    def _ulysses_ok(self):
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return self.dit.num_heads % world == 0
+
+    def enable_sequence_parallel(self, cfg_parallel=1, attn_mode="allgather"):
+        """Shard the denoise loop over the default process group: world = cfg_parallel x sp.  cfg_parallel = 2 gives
+        each half of the ranks one CFG branch; inside a half (or the whole world) tokens are sharded by
+        latent-temporal ranges and self-attention exchanges by `attn_mode` ("allgather" K/V or "ulysses")."""
+        from .sequence_parallel import ParallelLayout
+        self.parallel = ParallelLayout(cfg_parallel, attn_mode)
+        self.sequence_shard = self.parallel.shard
         self.use_unified_sequence_parallel = True
         return self
 
@@ -305,8 +315,8 @@ class WanVideoPipeline(torch.nn.Module):
         return video
 
     def decode_latents(self, latents, tiled=True, tile_size=(30, 52), tile_stride=(15, 26)):
-        """vae.decode on the device (reference :322-323); tiles go round-robin over the sequence-parallel ranks."""
-        shard = self.sequence_shard if (self.sequence_shard is not None and self.sequence_shard.world_size > 1) else None
+        """vae.decode on the device (reference :322-323); tiles are dealt over all ranks."""
+        shard = self.parallel.world if (self.parallel is not None and self.parallel.world.world_size > 1) else None
         return self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
                                shard=shard)
 
@@ -331,10 +341,19 @@ class WanVideoPipeline(torch.nn.Module):
         interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not two_streams
         if two_streams and self._cfg_side_streams is None:
             self._cfg_side_streams = (torch.cuda.Stream(latents.device), torch.cuda.Stream(latents.device))
+        cfg_split = self.parallel is not None and self.parallel.cfg_parallel == 2 and self.model_fn is model_fn_wan_video
+        interleave = interleave and not cfg_split
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
-            if two_streams:
+            if cfg_split:
+                # this rank's half of the world computes ONE branch; one world all-gather exchanges the predictions
+                mine = inputs_posi if (self.parallel.branch == 0 or cfg_scale == 1.0) else inputs_nega
+                out_loc, grid = self.model_fn(**models, **shared, **inputs_posi_ctx(mine), timestep=ts, gather_output=False)
+                both = self.parallel.gather_branches(out_loc, grid[0] * grid[1] * grid[2])
+                posi = self.dit.unpatchify(both[0:1], grid).contiguous()
+                nega = self.dit.unpatchify(both[1:2], grid).contiguous() if cfg_scale != 1.0 else None
+            elif two_streams:
                 main = torch.cuda.current_stream(latents.device)
                 outs = []
                 for side, ctx in zip(self._cfg_side_streams, (inputs_posi, inputs_nega)):
@@ -367,11 +386,11 @@ def inputs_posi_ctx(d):
 
 # ------------------------------------------------------------------------------------- the DiT forward
 def model_fn_wan_video(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
-                       sequence_shard=None, **kwargs):
+                       sequence_shard=None, gather_output=True, **kwargs):
     """One DiT forward (TI2V-5B / T2V branches of pipelines/wan_video.py:1217-1388); see model_fn_wan_video_steps."""
     gen = model_fn_wan_video_steps(dit, latents=latents, timestep=timestep, context=context,
                                    fuse_vae_embedding_in_latents=fuse_vae_embedding_in_latents,
-                                   sequence_shard=sequence_shard, **kwargs)
+                                   sequence_shard=sequence_shard, gather_output=gather_output, **kwargs)
     while True:
         try:
             next(gen)
@@ -393,8 +412,9 @@ def run_interleaved(generators):
 
 
 def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
-                             sequence_shard=None, **kwargs):
-    """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction).
+                             sequence_shard=None, gather_output=True, **kwargs):
+    """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction, or
+    with gather_output=False the head output of this rank's tokens (1, n_local, out_dim*prod(patch)) and the grid).
 
     timestep: (1,) tensor already rounded to the pipeline dtype (host or device).  The per-token time embedding of
     the reference (:1219-1228) has only two distinct rows (t=0 for the first latent frame, t elsewhere): both rows
@@ -423,7 +443,11 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         x_loc = x[:, lo:hi].contiguous()
         out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
                                                       (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n)
+        if not gather_output:
+            return out_loc, (f, h, w)
         out = sequence_shard.all_gather_tokens(out_loc, n)
     else:
         out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin))
+        if not gather_output:
+            return out, (f, h, w)
     return dit.unpatchify(out, (f, h, w))

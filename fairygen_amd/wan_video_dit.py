@@ -202,18 +202,20 @@ class WanModel(nn.Module):
                 return done.value
 
     def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
-        """Generator form of the 30-block forward: yields right after each block's K/V all-gather has been STARTED
-        (token-sharded runs only), so a driver can interleave two independent forwards (the CFG branches) and let
-        one branch's compute hide the other's xGMI traffic.  Returns (StopIteration.value) the head output.
+        """Generator form of the 30-block forward: yields right after each of a block's exchanges has been STARTED
+        (token-sharded runs only: the K/V all-gather, or the two Ulysses all-to-alls), so a driver can interleave two
+        independent forwards (the CFG branches) and let one branch's compute hide the other's xGMI traffic.
+        Returns (StopIteration.value) the head output.
 
         x (1,n,dim) local tokens; context (1,L,dim) embedded text; t_rows (R,dim) distinct time embeddings
         (R = 1 or 2), mod_rows_t (R,6,dim) their projections; tokens < first_rows use row 0.
         rope = (cos, sin) for the LOCAL tokens.  shard: optional fairygen_amd.sequence_parallel.TokenShard —
-        K/V are all-gathered over it before self-attention (shard_total = N, all ranks' tokens)."""
+        its attn_mode picks the exchange around self-attention (shard_total = N, all ranks' tokens)."""
         c, nh, eps = self.dim, self.num_heads, self.eps
         cos, sin = rope
         x = x.contiguous()
         blocks = list(self.blocks)
+        sharded = shard is not None and shard.world_size > 1
         mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
         h = hip.ln_modulate(x, mods[0], 0, 1, eps)
         for i, blk in enumerate(blocks):
@@ -224,14 +226,27 @@ class WanModel(nn.Module):
             qkv = F.linear(h, wqkv, bqkv)
             k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
             v = qkv[..., 2 * c:]
-            pending = None
-            if shard is not None and shard.world_size > 1:
+            if not sharded:
+                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+                a = sa.attn(q, k, v)
+            elif shard.attn_mode == "ulysses":
+                # token shard -> head shard: all N tokens of 24/P heads; attention; head shard -> token shard
+                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+                pending = shard.ulysses_qkv_async(q, k, v, shard_total, nh)
+                yield i
+                qg, kg, vg = pending.wait()
+                o_full = shard.ulysses_out_buffer(shard_total, qg.shape[-1], qg)
+                hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0))
+                pending = shard.ulysses_out_async(o_full, shard_total, x.shape[1])
+                yield i
+                a = pending.wait()
+            else:
                 pending = shard.all_gather_kv_async(k, v, shard_total)
-            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
-            if pending is not None:
+                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
                 yield i
                 k, v = pending.wait()
-            y = F.linear(sa.attn(q, k, v), sa.o.weight, sa.o.bias)
+                a = sa.attn(q, k, v)
+            y = F.linear(a, sa.o.weight, sa.o.bias)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
             x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
             # --- cross attention (reference :170-185)

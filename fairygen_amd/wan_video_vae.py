@@ -395,8 +395,9 @@ class WanVideoVAE38(nn.Module):
     def tiled_decode(self, hidden_states, device, tile_size, tile_stride, shard=None):
         """Same tiles, masks and bf16 accumulation ORDER as the reference (:1103-1152), but the canvas lives in HBM
         (654 MB at 704x1280x121) instead of bouncing every tile through host memory.  With a multi-rank `shard`
-        (sequence_parallel.TokenShard) tile i is decoded by rank i % world and broadcast; every rank then blends
-        all tiles in the reference's order, so the result is identical to the single-GPU one."""
+        (sequence_parallel.TokenShard) the tiles are dealt to ranks by area (sequence_parallel.assign_tiles), decoded
+        and broadcast; every rank then blends all tiles in the reference's order, so the result is identical to the
+        single-GPU one."""
         _, _, T, H, W = hidden_states.shape
         up = self.upsampling_factor
         out_T = T * 4 - 3
@@ -405,15 +406,20 @@ class WanVideoVAE38(nn.Module):
         values = torch.zeros((1, 3, out_T, H * up, W * up), dtype=z.dtype, device=device)
         tasks = self.tile_tasks(H, W, tile_size, tile_stride)
         world, rank = (shard.world_size, shard.rank) if shard is not None else (1, 0)
+        if world > 1:
+            from .sequence_parallel import assign_tiles
+            owner = assign_tiles([(min(h_, H) - h) * (min(w_, W) - w) for h, h_, w, w_ in tasks], world)
+        else:
+            owner = [0] * len(tasks)
         tiles = {}
         for i, (h, h_, w, w_) in enumerate(tasks):
-            if i % world == rank:
+            if owner[i] == rank:
                 tiles[i] = self.model.decode(z[:, :, :, h:h_, w:w_].contiguous(), self.scale)
         for i, (h, h_, w, w_) in enumerate(tasks):
             if world > 1:
                 th, tw = (min(h_, H) - h) * up, (min(w_, W) - w) * up
                 tile = tiles.pop(i) if i in tiles else torch.empty((1, 3, out_T, th, tw), dtype=z.dtype, device=device)
-                shard.broadcast(tile, src=i % world)
+                shard.broadcast(tile, src=owner[i])
             else:
                 tile = tiles.pop(i)
             hip.vae_tile_accumulate(tile[0], values[0], weight[0, 0], h * up, w * up,

@@ -52,6 +52,94 @@ def test_token_shard_gloo(tmp_path, world, n_tokens, port):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
+def _ulysses_worker(rank, world, port, n_tokens, heads, result_dir):
+    """The Ulysses exchange: token shard -> head shard -> (oracle attention per head group) -> token shard must equal
+    full attention on the unsharded tensors; two exchanges in flight like the interleaved CFG branches."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd.sequence_parallel import TokenShard
+        from oracle import wan_dit
+        shard = TokenShard(attn_mode="ulysses")
+        d = 16
+        c = heads * d
+        q, k, qkv = seeded((1, n_tokens, c), 1), seeded((1, n_tokens, c), 2), seeded((1, n_tokens, 3 * c), 3)
+        v = qkv[..., 2 * c:]                                    # strided slice, like the fused QKV buffer
+        lo, hi = shard.local_range(n_tokens)
+        hl = shard.heads_local(heads)
+        g = hl * d
+        pend_a = shard.ulysses_qkv_async(q[:, lo:hi], k[:, lo:hi], v[:, lo:hi], n_tokens, heads)
+        pend_b = shard.ulysses_qkv_async(k[:, lo:hi], q[:, lo:hi], v[:, lo:hi], n_tokens, heads)
+        qg, kg, vg = pend_a.wait()
+        kb, qb, _ = pend_b.wait()
+        cols = slice(rank * g, (rank + 1) * g)
+        assert qg.shape == (1, n_tokens, g) and qg.stride(1) == 3 * g
+        assert torch.equal(qg, q[..., cols]) and torch.equal(kg, k[..., cols]) and torch.equal(vg, v[..., cols])
+        assert torch.equal(qb, q[..., cols]) and torch.equal(kb, k[..., cols])
+        o_full = shard.ulysses_out_buffer(n_tokens, g, qg)
+        o_full[:n_tokens] = wan_dit.attention(qg, kg, vg, hl)[0]
+        out = shard.ulysses_out_async(o_full, n_tokens, hi - lo).wait()
+        want = wan_dit.attention(q, k, v, heads)[:, lo:hi]
+        assert out.shape == want.shape
+        assert (out.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tokens,heads,port", [(2, 105, 4, 29634), (3, 10, 6, 29635), (4, 64, 4, 29636)])
+def test_ulysses_exchange_gloo(tmp_path, world, n_tokens, heads, port):
+    mp.spawn(_ulysses_worker, args=(world, port, n_tokens, heads, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def _layout_worker(rank, world, port, result_dir):
+    """world = cfg_parallel x sp: group membership, branch assignment and the one-collective exchange of predictions."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd.sequence_parallel import ParallelLayout
+        n, c = 21, 6                                            # ragged: chunk 11 -> 11 + 10
+        preds = [seeded((1, n, c), 40), seeded((1, n, c), 41)]  # positive / negative prediction
+        for mode in ("ulysses", "allgather"):
+            lay = ParallelLayout(cfg_parallel=2, attn_mode=mode)
+            sp = world // 2
+            assert (lay.sp, lay.branch, lay.shard.rank) == (sp, rank // sp, rank % sp)
+            assert lay.describe() == (f"cfg2xsp{sp}-{mode}" if sp > 1 else "cfg2xsp1")
+            lo, hi = lay.shard.local_range(n)
+            both = lay.gather_branches(preds[lay.branch][:, lo:hi], n)
+            assert both.shape == (2, n, c) and torch.equal(both[0], preds[0][0]) and torch.equal(both[1], preds[1][0])
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t, group=lay.shard.group)           # the subgroup really is this rank's half
+            assert t.item() == sum(range(lay.branch * sp, (lay.branch + 1) * sp))
+        one = ParallelLayout(cfg_parallel=1, attn_mode="ulysses")
+        assert one.branch is None and one.shard is one.world and one.describe() == f"cfg1xsp{world}-ulysses"
+        with pytest.raises(ValueError):
+            ParallelLayout(cfg_parallel=3)
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29637), (4, 29638)])
+def test_cfg_parallel_layout_gloo(tmp_path, world, port):
+    mp.spawn(_layout_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_assign_tiles_balances_by_area():
+    from fairygen_amd.sequence_parallel import assign_tiles
+    from fairygen_amd.wan_video_vae import WanVideoVAE38
+    tasks = WanVideoVAE38.tile_tasks(44, 80, (30, 52), (15, 26))                  # 704x1280: the reference's 6 tiles
+    costs = [(min(h_, 44) - h) * (min(w_, 80) - w) for h, h_, w, w_ in tasks]
+    assert costs == [1560, 1560, 840, 1508, 1508, 812]
+    for world, bound in ((1, 7788), (2, 3908), (4, 2348), (8, 1560)):
+        owner = assign_tiles(costs, world)
+        loads = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
+        assert sum(loads) == sum(costs) and max(loads) <= bound, (world, loads)
+    assert assign_tiles([], 4) == []
+
+
 def test_single_process_shard_is_identity():
     from fairygen_amd.sequence_parallel import TokenShard
     s = TokenShard()
@@ -82,20 +170,23 @@ def _gpu_worker(rank, world, port, result_dir):
         ts = torch.tensor([500.0]).to(torch.bfloat16)
         with torch.no_grad():
             full = model_fn_wan_video(m, latents=lat, timestep=ts, context=ctx, fuse_vae_embedding_in_latents=True)
-            shard = model_fn_wan_video(m, latents=lat, timestep=ts, context=ctx, fuse_vae_embedding_in_latents=True,
-                                       sequence_shard=TokenShard())
-        torch.cuda.synchronize()
-        err = (full.float() - shard.float()).abs().max().item()
-        assert err <= 2.0 ** -6 * full.float().abs().max().item(), f"sharded forward differs: {err}"
-        # the denoise loop: sharded runs interleave the two CFG branches around their K/V gathers
+            for mode in ("allgather", "ulysses"):
+                shard = model_fn_wan_video(m, latents=lat, timestep=ts, context=ctx, fuse_vae_embedding_in_latents=True,
+                                           sequence_shard=TokenShard(attn_mode=mode))
+                torch.cuda.synchronize()
+                err = (full.float() - shard.float()).abs().max().item()
+                assert err <= 2.0 ** -6 * full.float().abs().max().item(), f"sharded forward ({mode}) differs: {err}"
+        # the denoise loop: sharded runs interleave the two CFG branches around their exchanges; cfg_parallel=2 gives
+        # each half of the ranks one branch
         from fairygen_amd.wan_video import WanVideoPipeline
         ctx_n, z0 = seeded((1, 24, 128), 7).cuda(), seeded((1, 48, 1, 10, 14), 8).cuda()
+        layouts = [None, (1, "allgather"), (1, "ulysses"), (2, "allgather"), (2, "ulysses")]
         outs = []
-        for sharded in (False, True):
+        for layout in layouts:
             pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
             pipe.dit = m
-            if sharded:
-                pipe.enable_sequence_parallel()
+            if layout is not None:
+                pipe.enable_sequence_parallel(cfg_parallel=layout[0], attn_mode=layout[1])
             pipe.scheduler.set_timesteps(3, denoising_strength=1.0, shift=5.0)
             lat0 = lat.clone()
             lat0[:, :, 0:1] = z0
@@ -103,14 +194,16 @@ def _gpu_worker(rank, world, port, result_dir):
             with torch.no_grad():
                 outs.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
         torch.cuda.synchronize()
-        err = (outs[0].float() - outs[1].float()).abs().max().item()
-        assert err <= 0.05 * outs[0].float().abs().max().item(), f"sharded denoise loop differs: {err}"
+        for layout, out in zip(layouts[1:], outs[1:]):
+            err = (outs[0].float() - out.float()).abs().max().item()
+            assert err <= 0.05 * outs[0].float().abs().max().item(), f"sharded denoise loop {layout} differs: {err}"
         open(os.path.join(result_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_sharded_dit_forward_on_gpu(tmp_path):
-    mp.spawn(_gpu_worker, args=(2, 29641, str(tmp_path)), nprocs=2, join=True)
-    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(2))
+@pytest.mark.parametrize("world,port", [(2, 29641), (4, 29642)])
+def test_sharded_dit_forward_on_gpu(tmp_path, world, port):
+    mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
