@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void residual_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
                                                            const bf16* __restrict__ w, const double* __restrict__ ct,
                                                            const double* __restrict__ st, bf16* __restrict__ out,
-                                                           int64_t rows, int C, int head_dim, float eps) {
+                                                           int64_t rows, int C, int head_dim, float eps, int group_cols,
+                                                           int64_t out_group_stride, int64_t out_ld) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -196,8 +197,26 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restric
                     o[2 * j + 1] = (float)(bf16)(a * s + b * c);
                 }
             }
-            st8(out + row * C + (int64_t)vi * 8, o);
+            // column block g = col / group_cols goes to its own (rows, out_ld) plane (group_cols == C: plain rows)
+            const int col = vi * 8, g = col / group_cols;
+            st8(out + g * out_group_stride + row * out_ld + (col - g * group_cols), o);
         }
+    }
+}
+
+// dst[g][r][0..cols) = src[g][r][0..cols) with independent group / row strides on both sides (16-byte vectors):
+// the head-group <-> token re-layouts around the Ulysses all-to-alls.
+__global__ __launch_bounds__(256) void copy_groups_kernel(const bf16* __restrict__ src, int64_t sgs, int64_t sld,
+                                                          bf16* __restrict__ dst, int64_t dgs, int64_t dld, int groups,
+                                                          int64_t rows, int vec_per_row) {
+    const int64_t total = (int64_t)groups * rows * vec_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rg = i / vec_per_row;            // row-major over (row, group): a wave reads one source row
+        const int v = (int)(i - rg * vec_per_row);
+        const int64_t r = rg / groups;
+        const int g = (int)(rg - r * groups);
+        *reinterpret_cast<u32x4*>(dst + g * dgs + r * dld + v * 8) =
+            *reinterpret_cast<const u32x4*>(src + g * sgs + r * sld + v * 8);
     }
 }
 
@@ -323,8 +342,45 @@ int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight, const d
                  "fg_rmsnorm_rope_bf16: pointers / ldx must be 16-byte aligned");
     if (rows == 0) return FG_OK;
     hipLaunchKernelGGL(rmsnorm_rope_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps);
+                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
+                       (int64_t)C);
     return fg_launch_status("fg_rmsnorm_rope_bf16");
+}
+
+int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight, const double* cos_tab,
+                                 const double* sin_tab, void* out, int64_t rows, int C, int num_heads, float eps,
+                                 int group_cols, int64_t out_group_stride, int64_t out_ld, fg_stream_t stream) {
+    if (int e = check_rows("fg_rmsnorm_rope_grouped_bf16", rows, C, 1, 0)) return e;
+    FG_CHECK_ARG(x && weight && out, "fg_rmsnorm_rope_grouped_bf16: null pointer");
+    FG_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "fg_rmsnorm_rope_grouped_bf16: pass both tables or neither");
+    FG_CHECK_ARG(num_heads > 0 && C % num_heads == 0 && (C / num_heads) % 8 == 0,
+                 "fg_rmsnorm_rope_grouped_bf16: head_dim must be a multiple of 8");
+    FG_CHECK_ARG(group_cols > 0 && group_cols % 8 == 0 && C % group_cols == 0 && out_ld >= group_cols && out_ld % 8 == 0 &&
+                     out_group_stride % 8 == 0 && out_group_stride >= 0,
+                 "fg_rmsnorm_rope_grouped_bf16: group_cols must divide C; group_cols, out_ld, out_group_stride multiples of 8");
+    FG_CHECK_ARG(ldx >= C && ldx % 8 == 0 && FG_ALIGNED16(x) && FG_ALIGNED16(weight) && FG_ALIGNED16(out) &&
+                     FG_ALIGNED16(cos_tab) && FG_ALIGNED16(sin_tab),
+                 "fg_rmsnorm_rope_grouped_bf16: pointers / ldx must be 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
+                       out_group_stride, out_ld);
+    return fg_launch_status("fg_rmsnorm_rope_grouped_bf16");
+}
+
+int fg_copy_groups_bf16(const void* src, int64_t src_group_stride, int64_t src_ld, void* dst, int64_t dst_group_stride,
+                        int64_t dst_ld, int groups, int64_t rows, int cols, fg_stream_t stream) {
+    FG_CHECK_ARG(src && dst, "fg_copy_groups_bf16: null pointer");
+    FG_CHECK_ARG(groups > 0 && rows >= 0 && cols > 0 && cols % 8 == 0, "fg_copy_groups_bf16: cols must be a positive multiple of 8");
+    FG_CHECK_ARG(src_group_stride % 8 == 0 && src_ld % 8 == 0 && dst_group_stride % 8 == 0 && dst_ld % 8 == 0 &&
+                     src_ld >= cols && dst_ld >= cols && FG_ALIGNED16(src) && FG_ALIGNED16(dst),
+                 "fg_copy_groups_bf16: strides must be multiples of 8 elements, rows at least cols wide, pointers 16-byte aligned");
+    if (rows == 0) return FG_OK;
+    const int64_t total = (int64_t)groups * rows * (cols / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(copy_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, src_group_stride,
+                       src_ld, (bf16*)dst, dst_group_stride, dst_ld, groups, rows, cols / 8);
+    return fg_launch_status("fg_copy_groups_bf16");
 }
 
 int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t stream) {

@@ -24,6 +24,8 @@ _SIGNATURES = {
     "fg_gate_residual_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
     "fg_residual_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
     "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
+    "fg_rmsnorm_rope_grouped_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i64, _i64, _vp],
+    "fg_copy_groups_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
@@ -199,8 +201,11 @@ def residual_ln_affine(x, y, w, b, eps, mod=None, gate_idx=None, x_out=None, nor
     return x_out, norm_out
 
 
-def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None):
-    """x: (..., C) possibly a column slice of a wider row-major buffer (stride(-2) = ld)."""
+def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None, grouped=None):
+    """x: (..., C) possibly a column slice of a wider row-major buffer (stride(-2) = ld).
+
+    grouped=(dst, group_cols, group_stride, ld): write column block g of row r to the 1-D view
+    dst[g*group_stride + r*ld : ... + group_cols] instead of a (rows, C) tensor (Ulysses send buffer); returns dst."""
     _dev(x, "x"), _dev(weight, "weight")
     c = x.shape[-1]
     if x.stride(-1) != 1:
@@ -211,14 +216,37 @@ def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None):
     if x2.dim() != 2:
         raise HipLibraryError("rmsnorm_rope: strided input must be 2-D (rows, C) or (1, rows, C)")
     rows, ld = x2.shape[0], x2.stride(0)
-    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
+    if grouped is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
     if cos is not None:
         _dev(cos, "cos", torch.float64), _dev(sin, "sin", torch.float64)
         if cos.shape != (rows, c // num_heads // 2) or not cos.is_contiguous() or not sin.is_contiguous():
             raise HipLibraryError(f"rmsnorm_rope: rope tables must be ({rows}, {c // num_heads // 2}) contiguous")
+    if grouped is not None:
+        dst, group_cols, group_stride, out_ld = grouped
+        _dev(dst, "grouped dst")
+        groups = c // group_cols
+        if dst.dim() != 1 or dst.stride(0) != 1 or \
+                (groups - 1) * group_stride + max(rows - 1, 0) * out_ld + group_cols > dst.numel():
+            raise HipLibraryError("rmsnorm_rope: grouped destination too small for the requested layout")
+        _call("fg_rmsnorm_rope_grouped_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), _ptr(dst), rows, c,
+              num_heads, eps, group_cols, group_stride, out_ld, _stream(x))
+        return dst
     _call("fg_rmsnorm_rope_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), _ptr(out), rows, c, num_heads,
           eps, _stream(x))
     return out
+
+
+def copy_groups(src, src_group_stride, src_ld, dst, dst_group_stride, dst_ld, groups, rows, cols):
+    """dst[g*dst_group_stride + r*dst_ld + c] = src[g*src_group_stride + r*src_ld + c]; src / dst are 1-D views that
+    start at the first element to move (strides in elements)."""
+    _dev(src, "src"), _dev(dst, "dst")
+    for t, gs, ld, name in ((src, src_group_stride, src_ld, "src"), (dst, dst_group_stride, dst_ld, "dst")):
+        if t.dim() != 1 or t.stride(0) != 1 or (groups - 1) * gs + max(rows - 1, 0) * ld + cols > t.numel():
+            raise HipLibraryError(f"copy_groups: {name} view too small for the requested layout")
+    _call("fg_copy_groups_bf16", _ptr(src), src_group_stride, src_ld, _ptr(dst), dst_group_stride, dst_ld, groups, rows,
+          cols, _stream(src))
+    return dst
 
 
 def activation(x, kind, out=None):

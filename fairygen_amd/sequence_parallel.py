@@ -109,7 +109,27 @@ class TokenShard:
         """q, k, v (1, n_local, H*D) of this rank's tokens (v may be a column slice of a wider buffer).  Starts ONE
         all-to-all; `.wait()` -> (q, k, v) as (1, N, (H/P)*D) views (row stride 3*(H/P)*D) of ALL tokens for this
         rank's head group [rank*H/P, (rank+1)*H/P)."""
-        return _PendingQKV(self, q, k, v, n, num_heads)
+        p, size = self.world_size, self.chunk(n)
+        g = q.shape[-1] // num_heads * self.heads_local(num_heads)
+        n_loc = q.shape[1]
+        send = self.ulysses_send_buffer(n, q.shape[-1], q, n_loc)
+        for j, t in enumerate((q, k, v)):
+            send[:, :n_loc, j].copy_(t[0].unflatten(-1, (p, g)).transpose(0, 1))
+        return _PendingQKV(self, send, n)
+
+    def ulysses_send_buffer(self, n, c, like, n_local):
+        """(P, chunk, 3, C/P) all-to-all send buffer: block p = head group p of this rank's tokens, per token
+        [q_g | k_g | v_g]; rows >= n_local (short trailing ranks) are zeroed.  The device path fills it straight from
+        the RMSNorm+RoPE kernel (fg_rmsnorm_rope_grouped_bf16) and fg_copy_groups_bf16."""
+        p, size = self.world_size, self.chunk(n)
+        send = torch.empty((p, size, 3, c // p), dtype=like.dtype, device=like.device)
+        if n_local < size:
+            send[:, n_local:].zero_()
+        return send
+
+    def ulysses_exchange_async(self, send, n):
+        """Start the all-to-all of a filled send buffer; `.wait()` as for ulysses_qkv_async."""
+        return _PendingQKV(self, send, n)
 
     def ulysses_out_buffer(self, n, cols, like):
         """(P*chunk, cols) buffer for the head-group attention output: the kernel writes rows [0, N), the reverse
@@ -175,19 +195,11 @@ class _PendingQKV:
     columns).  Receive layout (P, chunk, 3, g) = (P*chunk tokens in global order, 3g): q / k / v of my head group
     are column slices with row stride 3g — the attention kernel takes leading dimensions, so nothing is repacked."""
 
-    def __init__(self, shard, q, k, v, n, num_heads):
-        p, size = shard.world_size, shard.chunk(n)
-        hl = shard.heads_local(num_heads)
-        c = q.shape[-1]
-        g = c // num_heads * hl
-        n_loc = q.shape[1]
+    def __init__(self, shard, send, n):
+        p, size, _, g = send.shape
+        assert (p, size) == (shard.world_size, shard.chunk(n)) and send.is_contiguous()
         self.n, self.g = n, g
-        send = torch.empty((p, size, 3, g), dtype=q.dtype, device=q.device)
-        if n_loc < size:
-            send[:, n_loc:].zero_()
-        for j, t in enumerate((q, k, v)):
-            send[:, :n_loc, j].copy_(t[0].unflatten(-1, (p, g)).transpose(0, 1))
-        self.recv = torch.empty((p * size, 3 * g), dtype=q.dtype, device=q.device)
+        self.recv = torch.empty((p * size, 3 * g), dtype=send.dtype, device=send.device)
         self._send = send
         self.work = _all_to_all_rows(shard, send.view(p * size, 3 * g), self.recv)
 
@@ -207,12 +219,15 @@ class _PendingOut:
         self.recv = torch.empty_like(o_full)
         self.work = _all_to_all_rows(shard, o_full, self.recv)
 
-    def wait(self):
+    def wait_blocks(self):
+        """-> (P, chunk, g): block p = head group p of this rank's tokens (rows >= n_local are padding)."""
         if self.work is not None:
             self.work.wait()
-        g = self.recv.shape[-1]
-        blocks = self.recv.view(self.p, self.size, g)[:, : self.n_local]          # (head group, token, g)
-        return blocks.transpose(0, 1).reshape(1, self.n_local, self.p * g)         # one copy: (token, all heads)
+        return self.recv.view(self.p, self.size, self.recv.shape[-1])
+
+    def wait(self):
+        blocks = self.wait_blocks()[:, : self.n_local]                              # (head group, token, g)
+        return blocks.transpose(0, 1).reshape(1, self.n_local, -1)                  # one copy: (token, all heads)
 
 
 # ---------------------------------------------------------------------------------------------- rank layout

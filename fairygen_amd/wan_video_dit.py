@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import hip
+from . import hip, tuning
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -224,23 +224,32 @@ class WanModel(nn.Module):
             sa, ca = blk.self_attn, blk.cross_attn
             # --- self attention (reference :139-146)
             qkv = F.linear(h, wqkv, bqkv)
-            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
             v = qkv[..., 2 * c:]
             if not sharded:
+                k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
                 q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
                 a = sa.attn(q, k, v)
             elif shard.attn_mode == "ulysses":
-                # token shard -> head shard: all N tokens of 24/P heads; attention; head shard -> token shard
-                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
-                pending = shard.ulysses_qkv_async(q, k, v, shard_total, nh)
+                # token shard -> head shard (all N tokens of 24/P heads), attention, head shard -> token shard.  The
+                # norm+RoPE kernels and one strided copy write q | k | v straight into the all-to-all send buffer.
+                n_loc, p_, size = x.shape[1], shard.world_size, shard.chunk(shard_total)
+                g = c // nh * shard.heads_local(nh)
+                send = shard.ulysses_send_buffer(shard_total, c, qkv, n_loc)           # (P, chunk, 3, g)
+                flat, layout = send.view(-1), (g, size * 3 * g, 3 * g)
+                hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin, grouped=(flat, *layout))
+                hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin, grouped=(flat[g:], *layout))
+                hip.copy_groups(qkv.view(-1)[2 * c:], g, 3 * c, flat[2 * g:], size * 3 * g, 3 * g, p_, n_loc, g)
+                pending = shard.ulysses_exchange_async(send, shard_total)
                 yield i
                 qg, kg, vg = pending.wait()
-                o_full = shard.ulysses_out_buffer(shard_total, qg.shape[-1], qg)
+                o_full = shard.ulysses_out_buffer(shard_total, g, qkv)
                 hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0))
-                pending = shard.ulysses_out_async(o_full, shard_total, x.shape[1])
+                pending = shard.ulysses_out_async(o_full, shard_total, n_loc)
                 yield i
-                a = pending.wait()
+                a = torch.empty((1, n_loc, c), dtype=qkv.dtype, device=qkv.device)
+                hip.copy_groups(pending.wait_blocks().view(-1), size * g, g, a.view(-1), g, c, p_, n_loc, g)
             else:
+                k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
                 pending = shard.all_gather_kv_async(k, v, shard_total)
                 q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
                 yield i
@@ -261,7 +270,7 @@ class WanModel(nn.Module):
                 f = torch._addmm_activation(blk.ffn[0].bias, h[0], blk.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
             else:
                 f = hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
-            y = F.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)
+            y = tuning.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)      # table: better hipBLASLt solution at shard sizes
             if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
                 x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])
             else:

@@ -80,6 +80,22 @@ int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight,
                          const double* cos_tab, const double* sin_tab, void* out,
                          int64_t rows, int C, int num_heads, float eps, fg_stream_t stream);
 
+/* Same arithmetic, head-group-major output for the sequence-parallel Ulysses exchange (the reference's
+ * xfuser path re-lays q/k out inside xFuserLongContextAttention, utils/xfuser/xdit_context_parallel.py:125-146):
+ * column block g = col / group_cols of row r is written to out + g*out_group_stride + r*out_ld + col % group_cols,
+ * i.e. straight into the all-to-all send buffer (block g = the heads of rank g). */
+int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight,
+                                 const double* cos_tab, const double* sin_tab, void* out,
+                                 int64_t rows, int C, int num_heads, float eps,
+                                 int group_cols, int64_t out_group_stride, int64_t out_ld, fg_stream_t stream);
+
+/* dst[g*dst_group_stride + r*dst_ld + c] = src[g*src_group_stride + r*src_ld + c] for g < groups, r < rows, c < cols
+ * (strides in elements): the v columns into the Ulysses send buffer, and the received head-group blocks back to
+ * "b s (n d)" rows before the o projection (xdit_context_parallel.py:139-145, the reference's rearranges). */
+int fg_copy_groups_bf16(const void* src, int64_t src_group_stride, int64_t src_ld,
+                        void* dst, int64_t dst_group_stride, int64_t dst_ld,
+                        int groups, int64_t rows, int cols, fg_stream_t stream);
+
 /* Elementwise activation, out may alias x.  kind 0: SiLU (time_embedding / time_projection,
  * models/wan_video_dit.py:312-318); kind 1: GELU(tanh) (ffn / text_embedding, :208-209,307-311). */
 int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t stream);

@@ -114,6 +114,34 @@ def test_rmsnorm_rope(hip, heads, C, grid):
     assert_close_bf16(got, wan_dit.rms_norm(wide[..., :C], wt, 1e-6), 1.0, "rmsnorm")
 
 
+def test_ulysses_packing_kernels(hip):
+    """fg_rmsnorm_rope_grouped_bf16 / fg_copy_groups_bf16: the head-group-major layouts around the Ulysses all-to-alls
+    are exact re-layouts of the plain kernels' results (bit-exact), including a short (padded) token shard."""
+    heads, C, P, n, size = 4, 512, 2, 15, 17            # 2 head groups of 256 columns; 15 tokens in a 17-row chunk
+    g = C // P
+    f, h, w_ = 1, 3, 5
+    qkv = dev(seeded((1, n, 3 * C), 31))
+    wt = dev((1 + 0.1 * seeded((C,), 32)).to(torch.bfloat16))
+    table = wan_dit.rope_table_3d(C // heads, f, h, w_)
+    cos, sin = dev(table.real.reshape(n, -1).contiguous()), dev(table.imag.reshape(n, -1).contiguous())
+    send = torch.full((P, size, 3, g), 7.0, dtype=torch.bfloat16, device="cuda")
+    flat, layout = send.view(-1), (g, size * 3 * g, 3 * g)
+    hip.rmsnorm_rope(qkv[..., :C], wt, heads, 1e-6, cos, sin, grouped=(flat, *layout))
+    hip.rmsnorm_rope(qkv[..., C:2 * C], wt, heads, 1e-6, grouped=(flat[g:], *layout))
+    hip.copy_groups(qkv.view(-1)[2 * C:], g, 3 * C, flat[2 * g:], size * 3 * g, 3 * g, P, n, g)
+    q = hip.rmsnorm_rope(qkv[..., :C], wt, heads, 1e-6, cos, sin)[0]
+    k = hip.rmsnorm_rope(qkv[..., C:2 * C], wt, heads, 1e-6)[0]
+    for j, t in enumerate((q, k, qkv[0, :, 2 * C:])):
+        assert torch.equal(send[:, :n, j], t.unflatten(-1, (P, g)).transpose(0, 1)), f"send block {j}"
+    assert (send[:, n:] == 7.0).all(), "rows past the shard must not be written"
+    blocks = dev(seeded((P, size, g), 33))               # received head-group blocks -> "b s (n d)" rows
+    a = torch.empty((1, n, C), dtype=torch.bfloat16, device="cuda")
+    hip.copy_groups(blocks.view(-1), size * g, g, a.view(-1), g, C, P, n, g)
+    assert torch.equal(a[0], blocks[:, :n].transpose(0, 1).reshape(n, C))
+    with pytest.raises(hip.HipLibraryError):
+        hip.copy_groups(blocks.view(-1), size * g, g, a.view(-1)[:-8], g, C, P, n, g)
+
+
 def test_activations_and_cfg_euler(hip):
     x = seeded((3, 1000, 8), 14, scale=3.0)
     assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu", max_mismatch=0.05)          # __expf vs libm: rare 1-ulp flips

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--kt", type=int, default=3)
     ap.add_argument("--ks", type=int, default=3)
     ap.add_argument("--rows", type=int, default=27280)
+    ap.add_argument("--interleaved", action="store_true")
     a = ap.parse_args()
     hip.load()
     dev = "cuda"
@@ -50,8 +51,13 @@ def main():
     rnd = lambda *s: torch.randn(s, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)  # noqa: E731
     if a.what == "attn":
         c = a.heads * 128
-        q, k, v = rnd(1, a.nq, c), rnd(1, a.nkv, c), rnd(1, a.nkv, c)
-        out = torch.empty_like(q)
+        if a.interleaved:      # q | k | v column slices of one (N, 3c) buffer, as after the Ulysses all-to-all
+            assert a.nq == a.nkv
+            qkv = rnd(1, a.nq, 3 * c)
+            q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        else:
+            q, k, v = rnd(1, a.nq, c), rnd(1, a.nkv, c), rnd(1, a.nkv, c)
+        out = torch.empty((1, a.nq, c), dtype=torch.bfloat16, device=dev)
         med, mn = timeit(lambda: hip.attention(q, k, v, a.heads, out=out), a.iters)
         fl = 4.0 * a.nq * a.nkv * c
         print(f"attn nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
