@@ -84,6 +84,23 @@ __host__ __device__ constexpr int exps_before(int g) {
 }
 static_assert(exps_before(27) == 32, "the last exponential must be issued by gap 26 (its pack feeds the MFMA of gap 28)");
 
+#ifndef FG_PK
+#define FG_PK 0           // 1: v_pk_fma_f32 / v_pk_add_f32 on element pairs (two exponent arguments / two row-sum terms per issue).
+#endif                    // Measured SLOWER (1155 -> 1067 TFLOP/s): tools/probes/valu_rate.hip shows a wave issues one VALU op per
+                          // ~5.4 clocks whether it is packed or not and v_exp_f32 per 8.5, and the pairs tie the schedule down.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Packed fp32 ops as opaque single instructions (placed in a chosen MFMA gap like the other asm helpers).
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float add_f32(float a, float b) {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -336,6 +353,23 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
             va[p].h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + v_rd1 + 4096 * (p >> 2) + 512 * (p & 3)));
         };
         // exponential e (0..31) = element (sub = e >> 4, j = e & 15); pair unit u = e >> 1 -> word (u & 3) of pf[u >> 2]
+#if FG_PK
+        // Pairs (2u, 2u+1) are adjacent accumulator registers: one v_pk_fma_f32 makes both exponent arguments (issued with
+        // the first exponential of the pair), one v_pk_add_f32 adds both terms to a two-lane row sum (issued with the pack).
+        const f32x2 scale2 = {scale_log2e, scale_log2e}, nmb2 = {-mb, -mb};
+        f32x2 ea[16], ps2 = {0.f, 0.f};
+        // the packed FMA of a pair is issued one gap BEFORE the gap of its first exponential (no dependent issue stall)
+        auto do_fma = [&](int u) {
+            const int sub = u >> 3, j = (2 * u) & 15;
+            ea[u] = pk_fma(f32x2{sc[0][sub][j], sc[0][sub][j + 1]}, scale2, nmb2);
+        };
+        auto do_exp = [&](int e) { pe[e] = fast_exp2((e & 1) ? ea[e >> 1].y : ea[e >> 1].x); };
+        auto do_add = [&](int e) {};
+        auto do_pack = [&](int u) {
+            pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]);
+            ps2 = pk_add(ps2, f32x2{pe[2 * u], pe[2 * u + 1]});
+        };
+#else
         auto do_exp = [&](int e) {
             const float p = fast_exp2(sc[0][e >> 4][e & 15] * scale_log2e - mb);
             pe[e] = p;
@@ -345,8 +379,12 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
         // pass does not look inside inline asm.
         auto do_add = [&](int e) { if (e & 1) ps1 = add_f32(ps1, pe[e]); else ps0 = add_f32(ps0, pe[e]); };
         auto do_pack = [&](int u) { pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]); };
+#endif
 
         static_for<0, FG_KDIST>([&](auto i) { read_k(decltype(i)::value); });
+#if FG_PK
+        static_for<0, (exps_before(1) + 1) / 2>([&](auto i) { do_fma(decltype(i)::value); });
+#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 32>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -365,6 +403,14 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
                 o[0][p & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[p].f, pf[p >> 2].f, o[0][p & 3], 0, 0, 0);
             }
             if constexpr (g + FG_VDIST >= 16 && g + FG_VDIST < 32) read_v(g + FG_VDIST - 16);
+#if FG_PK
+            {   // pairs whose first exponential belongs to the NEXT gap: [ (e1+1)/2, (e2+1)/2 )
+                constexpr int e2 = exps_before(g + 2);
+                constexpr int f0 = (e1 + 1) / 2, f1 = (e2 + 1) / 2;
+                if constexpr (f1 > f0) do_fma(f0);
+                if constexpr (f1 > f0 + 1) do_fma(f0 + 1);
+            }
+#endif
             // pack unit u in the first gap that starts with both of its exponentials issued (after this gap's MFMA: the
             // packed word is first used by a later gap's MFMA)
             constexpr int u0 = ep / 2, u1 = e0 / 2;
@@ -383,7 +429,11 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
             if constexpr (g == 30) write_v(cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         });
+#if FG_PK
+        l_run[0] += ps2.x + ps2.y;
+#else
         l_run[0] += ps0 + ps1;
+#endif
         if (!kTail) {
             absorb_max(pair_max(fmaxf(mt, sn[0][1][15])));
         } else if (t + 1 < t_end) {
