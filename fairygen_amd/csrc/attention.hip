@@ -101,6 +101,14 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     return r;
 }
 
+#ifndef FG_DOT2
+#define FG_DOT2 0         // 1: row sum from the packed bf16 P words with v_dot2c_f32_bf16 (16 instead of 32 VALU ops per tile; the sum
+#endif                    // is then over the bf16-rounded probabilities, the same values the PV product uses)
+__device__ __forceinline__ float dot2c_bf16(uint32_t a, uint32_t b, float acc) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+
 __device__ __forceinline__ float add_f32(float a, float b) {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -377,8 +385,21 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
         // Row-sum add as opaque asm (no SLP packing / sinking to the end of the step).  Issued one gap AFTER the exponential:
         // gfx950 needs a wait state between a transcendental and a VALU reader of its result, and the compiler's hazard
         // pass does not look inside inline asm.
+#if FG_DOT2
+        // the packed word of pair u is summed one pack later (no dependent issue right behind the conversion)
+        const uint32_t ones = 0x3f803f80u;
+        auto do_add = [&](int e) {};
+        auto do_pack = [&](int u) {
+            pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]);
+            if (u > 0) {
+                if (u & 1) ps1 = dot2c_bf16(pf[(u - 1) >> 2].w[(u - 1) & 3], ones, ps1);
+                else ps0 = dot2c_bf16(pf[(u - 1) >> 2].w[(u - 1) & 3], ones, ps0);
+            }
+        };
+#else
         auto do_add = [&](int e) { if (e & 1) ps1 = add_f32(ps1, pe[e]); else ps0 = add_f32(ps0, pe[e]); };
         auto do_pack = [&](int u) { pf[u >> 2].w[u & 3] = cvt_pk_bf16(pe[2 * u], pe[2 * u + 1]); };
+#endif
 #endif
 
         static_for<0, FG_KDIST>([&](auto i) { read_k(decltype(i)::value); });
@@ -432,6 +453,9 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
 #if FG_PK
         l_run[0] += ps2.x + ps2.y;
 #else
+#if FG_DOT2
+        ps1 = dot2c_bf16(pf[3].w[3], 0x3f803f80u, ps1);      // pair 15
+#endif
         l_run[0] += ps0 + ps1;
 #endif
         if (!kTail) {

@@ -27,6 +27,86 @@ from .lora import GeneralLoRALoader
 from .wan_video_dit import WanModel, sinusoidal_embedding_1d
 
 
+# ------------------------------------------------------------------------------------ TeaCache
+class TimeModulation:
+    """The time modulation t_mod in the form this build keeps it: `rows` (R, 6, dim) distinct rows instead of the
+    reference's per-token (1, N, 6, dim) tensor — R = 2 in TI2V mode (row 0 for the `first_rows` tokens of the pinned
+    first latent frame, row 1 for the other n - first_rows), R = 1 otherwise."""
+
+    def __init__(self, rows, first_rows, n):
+        self.rows, self.first_rows, self.n = rows, int(first_rows), int(n)
+
+    def clone(self):
+        return TimeModulation(self.rows.clone(), self.first_rows, self.n)
+
+    def rel_l1_to(self, prev):
+        """((self - prev).abs().mean() / prev.abs().mean()).item() of the dense tensors, computed from the rows: the bf16
+        elementwise difference, fp32 sums weighted by how many tokens use each row, bf16 means, bf16 quotient."""
+        d = (self.rows - prev.rows).abs().float().sum(dim=(1, 2))
+        p = prev.rows.abs().float().sum(dim=(1, 2))
+        if self.rows.shape[0] == 2:
+            w = torch.tensor([self.first_rows, self.n - self.first_rows], dtype=torch.float32, device=d.device)
+            d, p, count = (d * w).sum(), (p * w).sum(), float(self.n)
+        else:
+            d, p, count = d.sum(), p.sum(), 1.0
+        per = count * self.rows.shape[1] * self.rows.shape[2]
+        dt = self.rows.dtype
+        return ((d / per).to(dt) / (p / per).to(dt)).cpu().item()
+
+
+class TeaCache:
+    """pipelines/wan_video.py:1016-1065: skip the DiT blocks of a step while the accumulated polynomial-rescaled
+    relative L1 change of the time modulation stays under `rel_l1_thresh`; one instance per CFG branch."""
+
+    coefficients_dict = {
+        "Wan2.1-T2V-1.3B": [-5.21862437e+04, 9.23041404e+03, -5.28275948e+02, 1.36987616e+01, -4.99875664e-02],
+        "Wan2.1-T2V-14B": [-3.03318725e+05, 4.90537029e+04, -2.65530556e+03, 5.87365115e+01, -3.15583525e-01],
+        "Wan2.1-I2V-14B-480P": [2.57151496e+05, -3.54229917e+04, 1.40286849e+03, -1.35890334e+01, 1.32517977e-01],
+        "Wan2.1-I2V-14B-720P": [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02],
+    }
+
+    def __init__(self, num_inference_steps, rel_l1_thresh, model_id):
+        if model_id not in self.coefficients_dict:
+            supported = ", ".join(self.coefficients_dict)
+            raise ValueError(f"{model_id} is not a supported TeaCache model id. Please choose a valid model id in ({supported}).")
+        self.num_inference_steps, self.rel_l1_thresh = num_inference_steps, rel_l1_thresh
+        self.coefficients = self.coefficients_dict[model_id]
+        self.step = 0
+        self.accumulated_rel_l1_distance = 0
+        self.previous_modulated_input = self.previous_residual = self.previous_hidden_states = None
+
+    def check(self, dit, x, t_mod):
+        """True -> skip the blocks this step.  t_mod: TimeModulation (or a dense tensor laid out like the reference's)."""
+        modulated_inp = t_mod.clone()
+        if self.step == 0 or self.step == self.num_inference_steps - 1:
+            should_calc = True
+            self.accumulated_rel_l1_distance = 0
+        else:
+            if isinstance(modulated_inp, TimeModulation):
+                rel = modulated_inp.rel_l1_to(self.previous_modulated_input)
+            else:
+                prev = self.previous_modulated_input
+                rel = ((modulated_inp - prev).abs().mean() / prev.abs().mean()).cpu().item()
+            self.accumulated_rel_l1_distance += np.poly1d(self.coefficients)(rel)
+            should_calc = not (self.accumulated_rel_l1_distance < self.rel_l1_thresh)
+            if should_calc:
+                self.accumulated_rel_l1_distance = 0
+        self.previous_modulated_input = modulated_inp
+        self.step += 1
+        if self.step == self.num_inference_steps:
+            self.step = 0
+        if should_calc:
+            self.previous_hidden_states = x.clone()
+        return not should_calc
+
+    def store(self, hidden_states):
+        self.previous_residual = hidden_states - self.previous_hidden_states
+        self.previous_hidden_states = None
+
+    def update(self, hidden_states):
+        return hip.gate_residual(hidden_states.contiguous(), self.previous_residual)      # x + residual on the device
+
+
 # ------------------------------------------------------------------------------------ pipeline units
 class PipelineUnit:
     """diffusion/base_pipeline.py:12-56 — declarative (inputs -> outputs) step run before the loop."""
@@ -132,11 +212,28 @@ class WanVideoUnit_ImageEmbedderFused(PipelineUnit):
         return {"latents": latents, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z}
 
 
+class WanVideoUnit_TeaCache(PipelineUnit):
+    """:769-781 — one TeaCache per CFG branch when tea_cache_l1_thresh is given."""
+
+    def __init__(self):
+        super().__init__(seperate_cfg=True,
+                         input_params_posi={"num_inference_steps": "num_inference_steps", "tea_cache_l1_thresh": "tea_cache_l1_thresh",
+                                            "tea_cache_model_id": "tea_cache_model_id"},
+                         input_params_nega={"num_inference_steps": "num_inference_steps", "tea_cache_l1_thresh": "tea_cache_l1_thresh",
+                                            "tea_cache_model_id": "tea_cache_model_id"},
+                         output_params=("tea_cache",))
+
+    def process(self, pipe, num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id):
+        if tea_cache_l1_thresh is None:
+            return {}
+        return {"tea_cache": TeaCache(num_inference_steps, rel_l1_thresh=tea_cache_l1_thresh, model_id=tea_cache_model_id)}
+
+
 _OUT_OF_SCOPE_KWARGS = (
     "end_image", "input_video", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
     "control_video", "reference_image", "camera_control_direction", "vace_video", "vace_video_mask",
     "vace_reference_image", "animate_pose_video", "animate_face_video", "animate_inpaint_video", "animate_mask_video",
-    "vap_video", "motion_bucket_id", "longcat_video", "sliding_window_size", "sliding_window_stride", "tea_cache_l1_thresh",
+    "vap_video", "motion_bucket_id", "longcat_video", "sliding_window_size", "sliding_window_stride",
 )
 
 
@@ -162,6 +259,7 @@ class WanVideoPipeline(torch.nn.Module):
             WanVideoUnit_PromptEmbedder(),
             WanVideoUnit_InputVideoEmbedder(),
             WanVideoUnit_ImageEmbedderFused(),
+            WanVideoUnit_TeaCache(),
         ]
         self.post_units = []
         self.model_fn = model_fn_wan_video
@@ -260,8 +358,10 @@ class WanVideoPipeline(torch.nn.Module):
         pass        # models stay resident in HBM (no VRAM management on this path)
 
     def load_lora(self, module, lora_config=None, alpha=1, hotload=None, state_dict=None):
-        if hotload:
-            raise ValueError("VRAM Management is not enabled. LoRA hotloading is not supported.")
+        """base_pipeline.py:231-266.  hotload=None / False: fuse into the base weights (what inference.py does).
+        hotload=True: keep the adapter unfused next to the Linear (AutoWrappedLinear.lora_forward semantics,
+        core/vram/layers.py:417-436) so `clear_lora()` can drop it again.  The reference only allows that on modules
+        under its VRAM manager; here the weights are always resident in HBM, so any module with `add_hot_lora` takes it."""
         if state_dict is None:
             if isinstance(lora_config, str):
                 lora = load_state_dict(lora_config, torch_dtype=self.torch_dtype, device=self.device)
@@ -271,17 +371,32 @@ class WanVideoPipeline(torch.nn.Module):
         else:
             lora = state_dict
         loader = self.lora_loader(torch_dtype=self.torch_dtype, device=self.device)
-        loader.fuse_lora_to_base_model(module, loader.convert_state_dict(lora), alpha=alpha)
+        lora = loader.convert_state_dict(lora)
+        if hotload:
+            if not hasattr(module, "add_hot_lora"):
+                raise ValueError("VRAM Management is not enabled. LoRA hotloading is not supported.")
+            updated = 0
+            for name, sub in module.named_modules():
+                a_key, b_key = f"{name}.lora_A.weight", f"{name}.lora_B.weight"
+                if isinstance(sub, torch.nn.Linear) and a_key in lora and b_key in lora:
+                    module.add_hot_lora(name, lora[a_key].to(self.torch_dtype) * alpha, lora[b_key])
+                    updated += 1
+            print(f"{updated} tensors are patched by LoRA. You can use `pipe.clear_lora()` to clear all LoRA layers.")
+        else:
+            loader.fuse_lora_to_base_model(module, lora, alpha=alpha)
 
     def clear_lora(self):
-        print("0 LoRA layers are cleared.")      # fused LoRA cannot be cleared (same as the reference)
+        """base_pipeline.py:269-279: drop every hot-loaded adapter (fused ones cannot be cleared, as in the reference)."""
+        cleared = sum(m.clear_hot_loras() for m in self.modules() if hasattr(m, "clear_hot_loras"))
+        print(f"{cleared} LoRA layers are cleared.")
 
     # ----------------------------------------------------------------------------- __call__
     @torch.no_grad()
     def __call__(self, prompt, negative_prompt="", input_image=None, seed=None, rand_device="cpu", height=480, width=832,
                  num_frames=81, cfg_scale=5.0, cfg_merge=False, switch_DiT_boundary=0.875, num_inference_steps=50,
                  sigma_shift=5.0, denoising_strength=1.0, tiled=True, tile_size=(30, 52), tile_stride=(15, 26),
-                 progress_bar_cmd=tqdm, output_type="quantized", first_frame_latents=None, **other):
+                 tea_cache_l1_thresh=None, tea_cache_model_id="", progress_bar_cmd=tqdm, output_type="quantized",
+                 first_frame_latents=None, **other):
         for name, value in other.items():
             if name not in _OUT_OF_SCOPE_KWARGS:
                 raise TypeError(f"__call__() got an unexpected keyword argument {name!r}")
@@ -291,8 +406,10 @@ class WanVideoPipeline(torch.nn.Module):
             raise NotImplementedError("cfg_merge=True (batched CFG) is not on the reference inference.py path")
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
 
-        inputs_posi = {"prompt": prompt}
-        inputs_nega = {"negative_prompt": negative_prompt}
+        tea = {"tea_cache_l1_thresh": tea_cache_l1_thresh, "tea_cache_model_id": tea_cache_model_id,
+               "num_inference_steps": num_inference_steps}
+        inputs_posi = {"prompt": prompt, **tea}
+        inputs_nega = {"negative_prompt": negative_prompt, **tea}
         inputs_shared = {
             "input_image": input_image, "first_frame_latents": first_frame_latents, "input_video": None,
             "seed": seed, "rand_device": rand_device, "height": height, "width": width, "num_frames": num_frames,
@@ -381,7 +498,11 @@ class WanVideoPipeline(torch.nn.Module):
 
 
 def inputs_posi_ctx(d):
-    return {"context": d["context"]}
+    """The per-branch model_fn inputs: the embedded prompt and, when enabled, this branch's TeaCache."""
+    out = {"context": d["context"]}
+    if d.get("tea_cache") is not None:
+        out["tea_cache"] = d["tea_cache"]
+    return out
 
 
 # ------------------------------------------------------------------------------------- the DiT forward
@@ -412,7 +533,7 @@ def run_interleaved(generators):
 
 
 def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
-                             sequence_shard=None, gather_output=True, **kwargs):
+                             sequence_shard=None, gather_output=True, tea_cache=None, **kwargs):
     """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction, or
     with gather_output=False the head output of this rank's tokens (1, n_local, out_dim*prod(patch)) and the grid).
 
@@ -441,13 +562,16 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     if sequence_shard is not None and sequence_shard.world_size > 1:
         lo, hi = sequence_shard.local_range(n)
         x_loc = x[:, lo:hi].contiguous()
+        skip = tea_cache is not None and tea_cache.check(dit, x_loc, TimeModulation(mod_rows_t, first_rows, n))
         out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
-                                                      (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n)
+                                                      (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n,
+                                                      tea_cache, skip)
         if not gather_output:
             return out_loc, (f, h, w)
         out = sequence_shard.all_gather_tokens(out_loc, n)
     else:
-        out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin))
+        skip = tea_cache is not None and tea_cache.check(dit, x, TimeModulation(mod_rows_t, first_rows, n))
+        out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin), None, None, tea_cache, skip)
         if not gather_output:
             return out, (f, h, w)
     return dit.unpatchify(out, (f, h, w))

@@ -143,6 +143,8 @@ class WanModel(nn.Module):
         # (n, ffn) tensor, -1.9 % per forward; verified to be the tanh form, tools/gelu_epilogue_check.py; <= 1 bf16 ulp
         # from the reference's "round, then GELU" order).  False: GEMM, then fg_act_bf16 on the rounded output.
         self.gelu_epilogue = True
+        # hot-loaded (unfused) LoRA adapters: module name -> [(alpha*A (r,in), B (out,r)), ...]; see add_hot_lora
+        self.hot_loras = {}
 
     # ------------------------------------------------------------------ load-time hooks
     def invalidate_fused(self):
@@ -158,6 +160,32 @@ class WanModel(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self.invalidate_fused()
         self._rope_cache = {}
+        return out
+
+    # ------------------------------------------------------------------ hot-loaded LoRA (core/vram/layers.py:417-436)
+    def add_hot_lora(self, name, lora_a, lora_b):
+        """Attach an unfused adapter to Linear `name` ("blocks.3.self_attn.q", ...): its output becomes
+        linear(x) + x @ A^T @ B^T, evaluated left to right in the pipeline dtype like AutoWrappedLinear.lora_forward
+        (`lora_a` already carries alpha, base_pipeline.py:258).  Adapters stack; clear_hot_loras() removes them all."""
+        mod = dict(self.named_modules()).get(name)
+        if not isinstance(mod, nn.Linear):
+            raise KeyError(f"{name} is not a Linear of this model")
+        if lora_a.shape[1] != mod.in_features or lora_b.shape[0] != mod.out_features or lora_a.shape[0] != lora_b.shape[1]:
+            raise ValueError(f"LoRA shapes {tuple(lora_a.shape)}, {tuple(lora_b.shape)} do not fit {name} "
+                             f"({mod.in_features} -> {mod.out_features})")
+        w = mod.weight
+        self.hot_loras.setdefault(name, []).append((lora_a.to(device=w.device, dtype=w.dtype).contiguous(),
+                                                    lora_b.to(device=w.device, dtype=w.dtype).contiguous()))
+
+    def clear_hot_loras(self):
+        n = len(self.hot_loras)
+        self.hot_loras = {}
+        return n
+
+    def _hot(self, name, x, out):
+        """out (+)= sum of the adapters of `name` applied to x; `out` may be a column slice of a fused projection."""
+        for a, b in self.hot_loras.get(name, ()):
+            out += (x @ a.T) @ b.T
         return out
 
     # ------------------------------------------------------------------ host-side tables
@@ -192,16 +220,18 @@ class WanModel(nn.Module):
         return x.reshape(b, self.out_dim, f * px, h * py, w * pz)
 
     # ------------------------------------------------------------------ the 30-block token forward
-    def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
+    def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None, tea_cache=None,
+                       skip_blocks=False):
         """Run forward_tokens_steps to completion (single branch)."""
-        gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total)
+        gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total, tea_cache, skip_blocks)
         while True:
             try:
                 next(gen)
             except StopIteration as done:
                 return done.value
 
-    def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None):
+    def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None,
+                             tea_cache=None, skip_blocks=False):
         """Generator form of the 30-block forward: yields right after each of a block's exchanges has been STARTED
         (token-sharded runs only: the K/V all-gather, or the two Ulysses all-to-alls), so a driver can interleave two
         independent forwards (the CFG branches) and let one branch's compute hide the other's xGMI traffic.
@@ -210,20 +240,29 @@ class WanModel(nn.Module):
         x (1,n,dim) local tokens; context (1,L,dim) embedded text; t_rows (R,dim) distinct time embeddings
         (R = 1 or 2), mod_rows_t (R,6,dim) their projections; tokens < first_rows use row 0.
         rope = (cos, sin) for the LOCAL tokens.  shard: optional fairygen_amd.sequence_parallel.TokenShard —
-        its attn_mode picks the exchange around self-attention (shard_total = N, all ranks' tokens)."""
+        its attn_mode picks the exchange around self-attention (shard_total = N, all ranks' tokens).
+        tea_cache / skip_blocks: the wan_video.TeaCache of this CFG branch and its verdict for this step — a skipped step
+        re-applies the cached residual instead of running the 30 blocks, a computed one stores the new residual
+        (pipelines/wan_video.py:1297-1300,1316-1317,1375-1376)."""
         c, nh, eps = self.dim, self.num_heads, self.eps
         cos, sin = rope
         x = x.contiguous()
         blocks = list(self.blocks)
+        if skip_blocks:
+            blocks, x = [], tea_cache.update(x)
         sharded = shard is not None and shard.world_size > 1
+        hot = bool(self.hot_loras)
         mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
-        h = hip.ln_modulate(x, mods[0], 0, 1, eps)
+        h = hip.ln_modulate(x, mods[0], 0, 1, eps) if blocks else None
         for i, blk in enumerate(blocks):
             mod = mods[i]
             wqkv, bqkv, wkv_c, bkv_c = blk.fused_weights()
             sa, ca = blk.self_attn, blk.cross_attn
             # --- self attention (reference :139-146)
             qkv = F.linear(h, wqkv, bqkv)
+            if hot:
+                for j, nm in enumerate(("q", "k", "v")):
+                    self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
             v = qkv[..., 2 * c:]
             if not sharded:
                 k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
@@ -256,25 +295,41 @@ class WanModel(nn.Module):
                 k, v = pending.wait()
                 a = sa.attn(q, k, v)
             y = F.linear(a, sa.o.weight, sa.o.bias)
+            if hot:
+                self._hot(f"blocks.{i}.self_attn.o", a, y)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
             x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
             # --- cross attention (reference :170-185)
-            qc = hip.rmsnorm_rope(F.linear(h, ca.q.weight, ca.q.bias), ca.norm_q.weight, nh, eps)
+            qc = F.linear(h, ca.q.weight, ca.q.bias)
             kvc = F.linear(context, wkv_c, bkv_c)
+            if hot:
+                self._hot(f"blocks.{i}.cross_attn.q", h, qc)
+                self._hot(f"blocks.{i}.cross_attn.k", context, kvc[..., :c])
+                self._hot(f"blocks.{i}.cross_attn.v", context, kvc[..., c:])
+            qc = hip.rmsnorm_rope(qc, ca.norm_q.weight, nh, eps)
             kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
-            y = F.linear(ca.attn(qc, kc, kvc[..., c:]), ca.o.weight, ca.o.bias)
+            ac = ca.attn(qc, kc, kvc[..., c:])
+            y = F.linear(ac, ca.o.weight, ca.o.bias)
+            if hot:
+                self._hot(f"blocks.{i}.cross_attn.o", ac, y)
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
             x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
             # --- ffn (reference :208-209,228)
-            if self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
+            if hot and f"blocks.{i}.ffn.0" in self.hot_loras:      # the adapter adds to the pre-activation: no epilogue fusion
+                f = hip.activation(self._hot(f"blocks.{i}.ffn.0", h, F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias)), "gelu_tanh")
+            elif self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
                 f = torch._addmm_activation(blk.ffn[0].bias, h[0], blk.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
             else:
                 f = hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
             y = tuning.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)      # table: better hipBLASLt solution at shard sizes
+            if hot:
+                self._hot(f"blocks.{i}.ffn.2", f, y)
             if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
                 x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])
             else:
                 x = hip.gate_residual(x, y, mod, 5, out=x)
+        if tea_cache is not None and blocks:
+            tea_cache.store(x)
         # --- head (reference :261-268): table (R,2,C) = modulation + t
         hm = hip.ModTable((self.head.modulation.to(t_rows.dtype) + t_rows.unsqueeze(1)).contiguous(), first_rows)
         h = hip.ln_modulate(x, hm, 0, 1, eps)

@@ -68,11 +68,75 @@ def save(name, tensors, meta):
     print(f"wrote {path}: {sum(v.numel() * v.element_size() for v in tensors.values()) / 1e3:.1f} kB")
 
 
+def section_serving(R):
+    """7. serving glue next to the loop: TeaCache step skipping (8-step CFG loop on the tiny DiT)."""
+    from fairygen_amd import synthetic
+    ref_dit, ref_pipe = R["dit"], R["pipe"]
+    kw = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(kw), seed=1234)
+    model = ref_dit.WanModel(**kw).to(torch.bfloat16).eval()
+    model.load_state_dict(sd)
+    lat = seeded((1, 48, 3, 8, 8), 1)
+    ctx_p = seeded((1, 16, 128), 2); ctx_p[:, 10:] = 0
+    ctx_n = seeded((1, 16, 128), 3); ctx_n[:, 12:] = 0
+    z0 = seeded((1, 48, 1, 8, 8), 4)
+    fn = ref_pipe.model_fn_wan_video
+    steps, thresh, model_id = 8, 25.0, "Wan2.1-I2V-14B-720P"      # synthetic weights: rescaled distances 8-21 per step -> a mix of skipped and computed steps
+    out = {}
+    for mode, fuse in (("ti2v", True), ("t2v", False)):
+        tea = [ref_pipe.TeaCache(steps, rel_l1_thresh=thresh, model_id=model_id) for _ in range(2)]
+        sched = R["sched"]("Wan")
+        sched.set_timesteps(steps, denoising_strength=1.0, shift=5.0)
+        latents = lat.clone()
+        if fuse:
+            latents[:, :, 0:1] = z0
+        skipped = []
+        with torch.no_grad():
+            for pid, timestep in enumerate(sched.timesteps):
+                t = timestep.unsqueeze(0).to(dtype=torch.bfloat16)
+                had = [tc.previous_residual is not None and tc.previous_hidden_states is None for tc in tea]
+                posi = fn(dit=model, latents=latents, timestep=t, context=ctx_p, fuse_vae_embedding_in_latents=fuse, tea_cache=tea[0])
+                nega = fn(dit=model, latents=latents, timestep=t, context=ctx_n, fuse_vae_embedding_in_latents=fuse, tea_cache=tea[1])
+                # a skipped step leaves previous_hidden_states None (check() only clones x when it computes)
+                skipped.append([int(tc.previous_hidden_states is None and h and tc.accumulated_rel_l1_distance != 0) for tc, h in zip(tea, had)])
+                pred = nega + 5.0 * (posi - nega)
+                latents = sched.step(pred, sched.timesteps[pid], latents)
+                if fuse:
+                    latents[:, :, 0:1] = z0
+                out[f"{mode}_step{pid}"] = latents.clone()
+                out[f"{mode}_acc{pid}"] = torch.tensor([float(tc.accumulated_rel_l1_distance) for tc in tea], dtype=torch.float64)
+        out[f"{mode}_skipped"] = torch.tensor(skipped)
+        print(mode, "skipped (posi, nega) per step:", skipped)
+    # hot-loaded LoRA: AutoWrappedLinear.forward = linear_forward, then lora_forward (core/vram/layers.py:410-436) with the
+    # lists load_lora fills (alpha folded into A, base_pipeline.py:258); two stacked adapters
+    from diffsynth.core.vram.layers import AutoWrappedLinear
+    x = seeded((1, 40, 256), 91)
+    w, b = seeded((384, 256), 92, scale=0.05), seeded((384,), 93, scale=0.1)
+    a1, b1 = seeded((4, 256), 94, scale=0.05), seeded((384, 4), 95, scale=0.05)
+    a2, b2 = seeded((8, 256), 96, scale=0.05), seeded((384, 8), 97, scale=0.05)
+    stub = types.SimpleNamespace(lora_merger=None, lora_A_weights=[a1 * 0.5, a2 * 2], lora_B_weights=[b1, b2])
+    out["hot_lora_out"] = AutoWrappedLinear.lora_forward(stub, x, torch.nn.functional.linear(x, w, b))
+    try:
+        ref_pipe.TeaCache(4, 0.1, "Wan2.2-TI2V-5B")
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+    save("serving.safetensors", out, {
+        "config": str(kw), "weights": "synthetic.random_state_dict(dit_shapes(TINY_DIT_KWARGS), seed=1234)",
+        "inputs": f"as dit_tiny.safetensors; {steps} steps cfg 5 shift 5; TeaCache(rel_l1_thresh={thresh}, model_id={model_id!r}) per CFG branch; "
+                  "t2v: fuse_vae_embedding_in_latents=False (no first-frame pin); hot LoRA: x=seeded((1,40,256),91) w=seed 92 x0.05 (384,256) "
+                  "b=seed 93 x0.1; adapters (A1 seed 94 (4,256), B1 seed 95, alpha 0.5), (A2 seed 96 (8,256), B2 seed 97, alpha 2), all x0.05",
+        "source": "diffsynth/pipelines/wan_video.py TeaCache :1016-1065, model_fn_wan_video :1297-1300,1316-1317,1375-1376; "
+                  "core/vram/layers.py AutoWrappedLinear.lora_forward :417-428; base_pipeline.py:249-262"})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = import_reference()
     from fairygen_amd import synthetic
+    if "--only-serving" in sys.argv:
+        return section_serving(R)
 
     # ------------------------------------------------------------------ 1. DiT primitives
     ref_dit = R["dit"]
@@ -256,6 +320,8 @@ def main():
     out["uint8_frames"] = torch.from_numpy(np.stack([np.array(f) for f in frames]))
     save("pixels.safetensors", out, {"inputs": "noise shape (1,48,2,4,4) seed 1; video=seeded((1,3,2,8,8),41,scale=0.7).clamp(-1.2,1.2)",
                                      "source": "diffsynth/diffusion/base_pipeline.py:128-143,171-176"})
+
+    section_serving(R)
 
 
 if __name__ == "__main__":

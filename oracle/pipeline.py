@@ -31,8 +31,14 @@ def generate_noise(shape, seed, dtype=torch.bfloat16):
 
 
 def denoise_loop(sd, cfg, latents, context_posi, context_nega, num_inference_steps, cfg_scale=5.0,
-                 sigma_shift=5.0, first_frame_latents=None, dtype=torch.bfloat16, record=None, num_blocks=None):
-    """wan_video.py:283-309 — per step: forward+, forward-, CFG combine, Euler step, re-pin frame 0."""
+                 sigma_shift=5.0, first_frame_latents=None, dtype=torch.bfloat16, record=None, num_blocks=None,
+                 tea_cache_l1_thresh=None, tea_cache_model_id=""):
+    """wan_video.py:283-309 — per step: forward+, forward-, CFG combine, Euler step, re-pin frame 0.
+    tea_cache_l1_thresh: one TeaCache per CFG branch (WanVideoUnit_TeaCache, :769-781)."""
+    tea_p = tea_n = None
+    if tea_cache_l1_thresh is not None:
+        tea_p = wan_dit.TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id)
+        tea_n = wan_dit.TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id)
     sigmas, timesteps = wan_sigmas(num_inference_steps, shift=sigma_shift)
     fuse = first_frame_latents is not None
     if fuse:
@@ -40,9 +46,9 @@ def denoise_loop(sd, cfg, latents, context_posi, context_nega, num_inference_ste
         latents[:, :, 0:1] = first_frame_latents
     for i, ts in enumerate(timesteps):
         t = ts.unsqueeze(0).to(dtype=dtype)                      # wan_video.py:293 (bf16 rounding)
-        posi = wan_dit.model_fn(sd, cfg, latents, t, context_posi, fuse, num_blocks)
+        posi = wan_dit.model_fn(sd, cfg, latents, t, context_posi, fuse, num_blocks, tea_cache=tea_p)
         if cfg_scale != 1.0:
-            nega = wan_dit.model_fn(sd, cfg, latents, t, context_nega, fuse, num_blocks)
+            nega = wan_dit.model_fn(sd, cfg, latents, t, context_nega, fuse, num_blocks, tea_cache=tea_n)
             pred = nega + cfg_scale * (posi - nega)
         else:
             pred = posi
@@ -96,6 +102,15 @@ def fuse_lora(sd, lora_sd, alpha=1.0):
         sd[wk] = sd[wk] + delta
         n += 1
     return n
+
+
+def hot_lora_linear(x, weight, bias, adapters):
+    """core/vram/layers.py:410-436 — unfused (hot-loaded) adapters: linear(x), then out + x @ A^T @ B^T per adapter, left to
+    right in the tensors' dtype; `adapters` = [(alpha * A, B), ...] as base_pipeline.py:258-259 stores them."""
+    out = torch.nn.functional.linear(x, weight, bias)
+    for a, b in adapters:
+        out = out + x @ a.T @ b.T
+    return out
 
 
 def merge_stage_loras(stage1, stage2):

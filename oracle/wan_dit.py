@@ -143,7 +143,53 @@ def unpatchify(x, grid, patch, out_dim):
     return x.reshape(b, out_dim, f * px, h * py, w * pz)
 
 
-def model_fn(sd, cfg, latents, timestep, context, fuse_vae_embedding_in_latents=True, num_blocks=None):
+class TeaCache:
+    """pipelines/wan_video.py:1016-1065 — skip the block stack when the accumulated, polynomial-rescaled relative L1
+    change of the time modulation since the last computed step stays under a threshold; a skipped step re-applies the
+    cached residual (x_after_blocks - x_before_blocks)."""
+
+    COEFFICIENTS = {
+        "Wan2.1-T2V-1.3B": [-5.21862437e+04, 9.23041404e+03, -5.28275948e+02, 1.36987616e+01, -4.99875664e-02],
+        "Wan2.1-T2V-14B": [-3.03318725e+05, 4.90537029e+04, -2.65530556e+03, 5.87365115e+01, -3.15583525e-01],
+        "Wan2.1-I2V-14B-480P": [2.57151496e+05, -3.54229917e+04, 1.40286849e+03, -1.35890334e+01, 1.32517977e-01],
+        "Wan2.1-I2V-14B-720P": [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02],
+    }
+
+    def __init__(self, num_inference_steps, rel_l1_thresh, model_id):
+        if model_id not in self.COEFFICIENTS:
+            raise ValueError(f"{model_id} is not a supported TeaCache model id. Please choose a valid model id in "
+                             f"({', '.join(self.COEFFICIENTS)}).")
+        self.num_inference_steps, self.rel_l1_thresh = num_inference_steps, rel_l1_thresh
+        self.coefficients = self.COEFFICIENTS[model_id]
+        self.step, self.accumulated = 0, 0
+        self.previous_modulated_input = self.previous_residual = self.previous_hidden_states = None
+
+    def check(self, x, t_mod):
+        """-> True when the blocks are to be SKIPPED this step (:1037-1058)."""
+        import numpy as np
+        if self.step == 0 or self.step == self.num_inference_steps - 1:
+            should_calc, self.accumulated = True, 0
+        else:
+            rel = ((t_mod - self.previous_modulated_input).abs().mean() / self.previous_modulated_input.abs().mean()).cpu().item()
+            self.accumulated += np.poly1d(self.coefficients)(rel)
+            should_calc = not (self.accumulated < self.rel_l1_thresh)
+            if should_calc:
+                self.accumulated = 0
+        self.previous_modulated_input = t_mod.clone()
+        self.step = (self.step + 1) % self.num_inference_steps
+        if should_calc:
+            self.previous_hidden_states = x.clone()
+        return not should_calc
+
+    def store(self, x):
+        self.previous_residual = x - self.previous_hidden_states
+        self.previous_hidden_states = None
+
+    def update(self, x):
+        return x + self.previous_residual
+
+
+def model_fn(sd, cfg, latents, timestep, context, fuse_vae_embedding_in_latents=True, num_blocks=None, tea_cache=None):
     """One DiT forward = model_fn_wan_video (wan_video.py:1217-1231,1236,1253-1275,1329-1362,1378,1387).
 
     cfg: dict with dim, num_heads, eps, patch_size, freq_dim, out_dim, seperated_timestep.
@@ -169,7 +215,12 @@ def model_fn(sd, cfg, latents, timestep, context, fuse_vae_embedding_in_latents=
     x, (f, h, w) = patchify_tokens(sd, latents, patch)
     table = rope_table_3d(dim // nh, f, h, w)
     nblocks = cfg["num_layers"] if num_blocks is None else num_blocks
-    for i in range(nblocks):
-        x = dit_block(sd, f"blocks.{i}", x, ctx, t_mod, table, nh, eps)
+    if tea_cache is not None and tea_cache.check(x, t_mod):        # wan_video.py:1297-1300,1316-1317
+        x = tea_cache.update(x)
+    else:
+        for i in range(nblocks):
+            x = dit_block(sd, f"blocks.{i}", x, ctx, t_mod, table, nh, eps)
+        if tea_cache is not None:                                   # :1375-1376
+            tea_cache.store(x)
     x = head(sd, x, t, eps)
     return unpatchify(x, (f, h, w), patch, cfg["out_dim"])

@@ -82,6 +82,96 @@ def test_tiny_denoise_loop_vs_golden(tiny_dit, golden):
     assert torch.equal(out2, out)
 
 
+def test_teacache_loop_vs_golden(tiny_dit, golden):
+    """pipe(..., tea_cache_l1_thresh=, tea_cache_model_id=) semantics: the product's TeaCache takes the reference's
+    skip decisions (golden: computed, skip, skip, computed, skip, computed, skip, computed) and the 8-step latents
+    stay within the end-to-end tolerance of the reference's bf16 run."""
+    from fairygen_amd.wan_video import TeaCache, WanVideoPipeline
+    g = golden("serving.safetensors")
+    m, sd, cfg = tiny_dit
+    lat, ctx_p, ctx_n, z0, _ = _tiny_inputs()
+    for mode, first in (("ti2v", z0), ("t2v", None)):
+        pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+        pipe.dit = m
+        pipe.scheduler.set_timesteps(8, denoising_strength=1.0, shift=5.0)
+        latents = lat.clone()
+        if first is not None:
+            latents[:, :, 0:1] = first
+        tea = [TeaCache(8, rel_l1_thresh=25.0, model_id="Wan2.1-I2V-14B-720P") for _ in range(2)]
+        skipped = []
+        orig = TeaCache.check
+
+        def spy(self, dit, x, t_mod, _orig=orig):
+            r = _orig(self, dit, x, t_mod)
+            skipped.append(int(r))
+            return r
+        TeaCache.check = spy
+        try:
+            shared = {"latents": latents.cuda(), "fuse_vae_embedding_in_latents": first is not None,
+                      "first_frame_latents": None if first is None else first.cuda()}
+            with torch.no_grad():
+                out = pipe.denoise(shared, {"context": ctx_p.cuda(), "tea_cache": tea[0]},
+                                   {"context": ctx_n.cuda(), "tea_cache": tea[1]}, 5.0, progress_bar_cmd=lambda x: x)
+        finally:
+            TeaCache.check = orig
+        assert skipped[0::2] == g[f"{mode}_skipped"][:, 0].tolist() and skipped[1::2] == g[f"{mode}_skipped"][:, 1].tolist()
+        assert cos(out, g[f"{mode}_step7"]) > 0.999, mode
+
+
+def test_lora_hotload_and_clear(golden):
+    """pipe.load_lora(..., hotload=True) keeps the adapters unfused (AutoWrappedLinear.lora_forward arithmetic, pinned by the
+    golden vector of one Linear), matches the fused model within bf16 noise, and pipe.clear_lora() restores the base
+    model bit for bit."""
+    from fairygen_amd.wan_video import WanVideoPipeline, model_fn_wan_video
+    from fairygen_amd.wan_video_dit import WanModel
+    g = golden("serving.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    lora = synthetic.random_lora(synthetic.dit_shapes(cfg), rank=4, seed=4321)
+    lat, ctx_p, _, _, ts = _tiny_inputs()
+
+    def fresh():
+        m = WanModel(**cfg)
+        m.load_state_dict(sd)
+        pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+        pipe.dit = m.to(device="cuda", dtype=torch.bfloat16).eval()
+        return pipe
+
+    def fwd(pipe):
+        with torch.no_grad():
+            return model_fn_wan_video(pipe.dit, latents=lat.cuda(), timestep=ts, context=ctx_p.cuda(), fuse_vae_embedding_in_latents=True)
+
+    base, fused, hot = fresh(), fresh(), fresh()
+    out_base = fwd(base)
+    fused.load_lora(fused.dit, state_dict=lora, alpha=2.0)
+    hot.load_lora(hot.dit, state_dict=lora, alpha=2.0, hotload=True)
+    assert len(hot.dit.hot_loras) == 10 * cfg["num_layers"]          # q,k,v,o x2 + ffn.0 + ffn.2 per block
+    out_fused, out_hot = fwd(fused), fwd(hot)
+    assert not torch.equal(out_hot, out_base)
+    assert cos(out_hot, out_fused) > 0.9995 and (out_hot.float() - out_fused.float()).abs().max().item() < 0.1
+    hot.clear_lora()
+    assert hot.dit.hot_loras == {} and torch.equal(fwd(hot), out_base)
+    with pytest.raises(ValueError, match="hotloading is not supported"):
+        hot.load_lora(torch.nn.Linear(4, 4), state_dict=lora, hotload=True)
+    # one Linear, two stacked adapters: the reference's own lora_forward output
+    x = seeded((1, 40, 256), 91).cuda()
+    lin = torch.nn.Linear(256, 384)
+    lin.weight.data, lin.bias.data = seeded((384, 256), 92, scale=0.05), seeded((384,), 93, scale=0.1)
+
+    class One(WanModel):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.proj, self.hot_loras = lin.to("cuda"), {}
+    one = One()
+    one.add_hot_lora("proj", seeded((4, 256), 94, scale=0.05) * 0.5, seeded((384, 4), 95, scale=0.05))
+    one.add_hot_lora("proj", seeded((8, 256), 96, scale=0.05) * 2, seeded((384, 8), 97, scale=0.05))
+    got = one._hot("proj", x, torch.nn.functional.linear(x, one.proj.weight, one.proj.bias))
+    want = g["hot_lora_out"]
+    assert (got.float().cpu() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+    with pytest.raises(ValueError):
+        one.add_hot_lora("proj", seeded((4, 128), 1), seeded((384, 4), 2))
+
+
 def test_medium_dit_block_stack_vs_oracle():
     """Full-width heads (24 x 128, dim 3072) but 2 layers / small ffn, ragged token count, vs the oracle."""
     from fairygen_amd.wan_video_dit import WanModel

@@ -172,3 +172,36 @@ def test_tile_grid_matches_oracle():
             assert WanVideoVAE38.tile_tasks(*hw, size, stride) == wan_vae.tile_tasks(*hw, size, stride)
     assert len(WanVideoVAE38.tile_tasks(44, 80, (30, 52), (15, 26))) == 6
     assert len(WanVideoVAE38.tile_tasks(30, 52, (30, 52), (15, 26))) == 1
+
+
+def test_teacache_rows_form_matches_dense():
+    """The product keeps the time modulation as 2 distinct rows; its relative-L1 statistic must equal the reference's
+    dense (1, N, 6, dim) computation, and the TeaCache state machine must take the same decisions from either form."""
+    from fairygen_amd.wan_video import TeaCache, TimeModulation
+    n, first, dim = 48, 16, 32
+    dense_of = lambda rows: torch.cat([rows[0:1].expand(first, -1, -1), rows[1:2].expand(n - first, -1, -1)]).unsqueeze(0)  # noqa: E731
+    seq = [seeded((2, 6, dim), 60 + i) * (1.0 + 0.05 * i) for i in range(6)]
+    for a, b in zip(seq, seq[1:]):
+        want = ((dense_of(b) - dense_of(a)).abs().mean() / dense_of(a).abs().mean()).item()
+        assert TimeModulation(b, first, n).rel_l1_to(TimeModulation(a, first, n)) == want
+    one = [seeded((1, 6, dim), 70 + i) for i in range(3)]
+    want = ((one[1] - one[0]).abs().mean() / one[0].abs().mean()).item()
+    assert TimeModulation(one[1], 0, n).rel_l1_to(TimeModulation(one[0], 0, n)) == want
+    x = seeded((1, n, dim), 80)
+    base = seeded((2, 6, dim), 90).float()
+    seq = [(base * (1.0 + 0.02 * i)).to(torch.bfloat16) for i in range(6)]       # ~2 % change per step: rescaled ~0.16
+    decisions = []
+    for form in ("rows", "dense"):
+        tc = TeaCache(len(seq), rel_l1_thresh=0.4, model_id="Wan2.1-I2V-14B-720P")
+        got = []
+        for rows in seq:
+            skip = tc.check(None, x, TimeModulation(rows, first, n) if form == "rows" else dense_of(rows))
+            got.append(skip)
+            if not skip:
+                tc.previous_residual = x             # what store() would leave behind
+                tc.previous_hidden_states = None
+        assert got[0] is False and got[-1] is False and tc.step == 0
+        decisions.append(got)
+    assert decisions[0] == decisions[1] == [False, True, True, False, True, False]
+    with pytest.raises(ValueError, match="not a supported TeaCache model id"):
+        TeaCache(4, 0.1, "Wan2.2-TI2V-5B")

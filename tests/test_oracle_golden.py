@@ -4,6 +4,7 @@ Same dtype + same op order => the bf16 comparisons are bit-exact; the two places
 formulation differs from the reference's module code by a mathematically equal rewrite are given a stated
 tolerance of one bf16 ulp.
 """
+import pytest
 import torch
 
 from conftest import seeded
@@ -50,6 +51,33 @@ def test_dit_tiny_forward_and_loop(golden):
     opipe.denoise_loop(sd, cfg, lat, ctx_p, ctx_n, 4, 5.0, 5.0, z0, record=rec)
     for i, r in enumerate(rec):
         assert torch.equal(r, g[f"loop_step{i}"]), f"loop step {i}"
+
+
+def test_teacache_loop(golden):
+    """TeaCache (step skipping) restatement == the reference's TeaCache inside its model_fn, step for step: same
+    skipped steps (the accumulated distances match) and bit-identical latents, in TI2V and T2V timestep modes."""
+    g = golden("serving.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    lat, ctx_p, ctx_n, z0, _ = _tiny_inputs()
+    assert g["ti2v_skipped"][:, 0].tolist() == [0, 1, 1, 0, 1, 0, 1, 0] and g["t2v_skipped"].sum().item() == 0
+    for mode, first in (("ti2v", z0), ("t2v", None)):
+        rec = []
+        opipe.denoise_loop(sd, cfg, lat, ctx_p, ctx_n, 8, 5.0, 5.0, first, record=rec,
+                           tea_cache_l1_thresh=25.0, tea_cache_model_id="Wan2.1-I2V-14B-720P")
+        for i, r in enumerate(rec):
+            assert torch.equal(r, g[f"{mode}_step{i}"]), f"{mode} step {i}"
+    with pytest.raises(ValueError):
+        wan_dit.TeaCache(4, 0.1, "Wan2.2-TI2V-5B")
+
+
+def test_hot_lora_linear(golden):
+    g = golden("serving.safetensors")
+    x = seeded((1, 40, 256), 91)
+    w, b = seeded((384, 256), 92, scale=0.05), seeded((384,), 93, scale=0.1)
+    a1, b1 = seeded((4, 256), 94, scale=0.05), seeded((384, 4), 95, scale=0.05)
+    a2, b2 = seeded((8, 256), 96, scale=0.05), seeded((384, 8), 97, scale=0.05)
+    assert torch.equal(opipe.hot_lora_linear(x, w, b, [(a1 * 0.5, b1), (a2 * 2, b2)]), g["hot_lora_out"])
 
 
 def test_scheduler(golden):
