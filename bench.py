@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
     ap.add_argument("--gelu-epilogue", type=int, default=1, help="0: separate GELU kernel after ffn.0 instead of the GEMM epilogue")
     ap.add_argument("--cfg-streams", type=int, default=-1, help="1: CFG branches on two HIP streams (experimental; default off)")
+    ap.add_argument("--linear-dtype", default="bf16", choices=("bf16", "fp8"),
+                    help="fp8: the reference's fp8 Linear mode for the DiT blocks (config 5's weight path); NOT the headline config")
     ap.add_argument("--layout", default=os.environ.get("FAIRYGEN_PARALLEL", "auto"), choices=("auto",) + LAYOUTS,
                     help="N>1: how the ranks are used (auto: time every candidate for one step in the warm-up, keep the fastest)")
     args = ap.parse_args()
@@ -201,6 +203,8 @@ def main():
     hip.load()
     pipe, cfg = build_pipeline(args, device)
     pipe.dit.gelu_epilogue = bool(args.gelu_epilogue)
+    if args.linear_dtype == "fp8":
+        pipe.dit.enable_fp8_linear(torch.float8_e4m3fn)
     if world > 1 and args.layout != "auto":
         cfgp, mode = args.layout.split("-")
         pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
@@ -291,7 +295,8 @@ def main():
             "metric": "decoded frames/sec (sec/clip in config), Wan2.2-TI2V-5B 704x1280x121 @ 50 steps",
             "value": round(F_ / t_clip, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_clip / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.linear_dtype == "bf16" else "fp8_e4m3fn block linears (reference fp8_linear), bf16 elsewhere",
+            "data": "synthetic",
             "config": {"workload": f"Wan2.2-TI2V-5B {H}x{W}x{F_} TI2V clip: {args.steps} denoise steps (CFG 5.0, 2 forwards/step) + "
                                    f"{'untiled' if args.untiled else 'tiled (30,52)/(15,26)'} VAE38 decode",
                        "sec_per_clip": round(t_clip, 2), "denoise_s": round(phase.get("denoise_s", t_clip), 2),

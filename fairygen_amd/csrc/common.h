@@ -41,6 +41,16 @@ static inline int fg_launch_status(const char* what) {
 // Round-to-nearest-even through bf16 (mirrors one PyTorch bf16 op boundary).
 __device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }
 
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+    const float u = kBeta * (x + kKappa * x * x * x);
+    // tanh(u) = 1 - 2/(1+exp(2u)); clamp keeps exp finite.
+    const float e = __expf(2.0f * fminf(u, 15.0f));
+    const float t = 1.0f - 2.0f / (1.0f + e);
+    return 0.5f * x * (1.0f + t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

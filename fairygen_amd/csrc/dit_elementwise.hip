@@ -220,15 +220,6 @@ __global__ __launch_bounds__(256) void copy_groups_kernel(const bf16* __restrict
     }
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-    const float u = kBeta * (x + kKappa * x * x * x);
-    // tanh(u) = 1 - 2/(1+exp(2u)); clamp keeps exp finite.
-    const float e = __expf(2.0f * fminf(u, 15.0f));
-    const float t = 1.0f - 2.0f / (1.0f + e);
-    return 0.5f * x * (1.0f + t);
-}
 
 template <int KIND>
 __global__ __launch_bounds__(256) void act_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int64_t nvec) {

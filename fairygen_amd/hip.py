@@ -26,6 +26,7 @@ _SIGNATURES = {
     "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_rmsnorm_rope_grouped_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i64, _i64, _vp],
     "fg_copy_groups_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
+    "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
@@ -247,6 +248,28 @@ def copy_groups(src, src_group_stride, src_ld, dst, dst_group_stride, dst_ld, gr
     _call("fg_copy_groups_bf16", _ptr(src), src_group_stride, src_ld, _ptr(dst), dst_group_stride, dst_ld, groups, rows,
           cols, _stream(src))
     return dst
+
+
+FP8_E4M3FN_MAX = 448.0
+
+
+def fp8_quant_rows(x, act=None):
+    """Per-row dynamic fp8 quantisation of AutoWrappedLinear.fp8_linear (core/vram/layers.py:331-342).
+    x (..., C) bf16 with dense last dim (may be a column slice, 2-D/3-D) -> (x_fp8 (rows, C) float8_e4m3fn,
+    scale_a (rows, 1) fp32).  act="gelu_tanh" applies the activation (rounded to bf16) before quantising."""
+    _dev(x, "x")
+    c = x.shape[-1]
+    if x.stride(-1) != 1:
+        raise HipLibraryError("fp8_quant_rows: last dim must be dense")
+    x2 = x.reshape(-1, c) if x.is_contiguous() else (x.squeeze(0) if x.dim() == 3 else x)
+    if x2.dim() != 2:
+        raise HipLibraryError("fp8_quant_rows: strided input must be 2-D (rows, C) or (1, rows, C)")
+    rows, ld = x2.shape[0], x2.stride(0)
+    out = torch.empty((rows, c), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((rows, 1), dtype=torch.float32, device=x.device)
+    _call("fg_fp8_quant_rows_bf16", _ptr(x2), ld, _ptr(out), _ptr(scale), None, rows, c,
+          {None: 0, "gelu_tanh": 1}[act], FP8_E4M3FN_MAX, _stream(x))
+    return out, scale
 
 
 def activation(x, kind, out=None):

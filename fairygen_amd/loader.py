@@ -196,8 +196,16 @@ class ModelPool:
             if cfg["model_hash"] != model_hash:
                 continue
             converter = _import(cfg["state_dict_converter"]) if "state_dict_converter" in cfg else None
+            # computation_dtype fp8 = the reference's fp8 Linear mode (AutoWrappedLinear.enable_fp8, core/vram/layers.py:312):
+            # parameters stay bf16 in HBM, the blocks' GEMMs run through torch._scaled_mm
+            comp = vram_config["computation_dtype"]
+            fp8 = comp in (torch.float8_e4m3fn, torch.float8_e4m3fnuz)
             model = load_model(_import(cfg["model_class"]), path, cfg.get("extra_kwargs", {}),
-                               vram_config["computation_dtype"], vram_config["computation_device"], converter)
+                               torch.bfloat16 if fp8 else comp, vram_config["computation_device"], converter)
+            if fp8:
+                if not hasattr(model, "enable_fp8_linear"):
+                    raise NotImplementedError(f"fp8 computation is only built for the DiT Linears, not for {cfg['model_name']}")
+                model.enable_fp8_linear(comp)
             self.model.append(model)
             self.model_name.append(cfg["model_name"])
             self.model_path.append(path)

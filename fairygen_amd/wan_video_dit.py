@@ -88,6 +88,17 @@ class DiTBlock(nn.Module):
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
         self._fused = None
+        self._fp8 = None
+
+    def fp8_weights(self, dtype):
+        """The block's Linear weights cast to fp8 once (the reference casts on every call, core/vram/layers.py:342 — same
+        values): [Wq;Wk;Wv], Wo, cross Wq, cross [Wk;Wv], cross Wo, ffn.0, ffn.2.  Rebuilt after load / LoRA fuse."""
+        if self._fp8 is None or self._fp8[0] != dtype:
+            wqkv, _, wkv_c, _ = self.fused_weights()
+            sa, ca = self.self_attn, self.cross_attn
+            ws = (wqkv, sa.o.weight, ca.q.weight, wkv_c, ca.o.weight, self.ffn[0].weight, self.ffn[2].weight)
+            self._fp8 = (dtype, tuple(w.to(dtype).contiguous() for w in ws))
+        return self._fp8[1]
 
     def fused_weights(self):
         """[Wq;Wk;Wv] and [Wk;Wv] (cross) concatenated once, so the three projections of a token tensor are
@@ -145,11 +156,15 @@ class WanModel(nn.Module):
         self.gelu_epilogue = True
         # hot-loaded (unfused) LoRA adapters: module name -> [(alpha*A (r,in), B (out,r)), ...]; see add_hot_lora
         self.hot_loras = {}
+        # fp8 Linear mode of the blocks (None = bf16 GEMMs); see enable_fp8_linear
+        self.fp8_dtype = None
+        self._ones = {}
 
     # ------------------------------------------------------------------ load-time hooks
     def invalidate_fused(self):
         for blk in self.blocks:
             blk._fused = None
+            blk._fp8 = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -161,6 +176,29 @@ class WanModel(nn.Module):
         self.invalidate_fused()
         self._rope_cache = {}
         return out
+
+    # ------------------------------------------------------------------ fp8 Linear mode (core/vram/layers.py:312,321-357)
+    def enable_fp8_linear(self, dtype=torch.float8_e4m3fn):
+        """Run the ten Linears of every DiT block like AutoWrappedLinear.fp8_linear when its computation_dtype is fp8:
+        per-row dynamic activation scale (fg_fp8_quant_rows_bf16), weights cast to e4m3 with unit scale, bf16 bias,
+        torch._scaled_mm (hipBLASLt fp8 MFMA) with bf16 output.  dtype None switches back to bf16 GEMMs.  The small
+        embedding / head Linears (< 1 % of the FLOPs) stay bf16.  gfx950's fp8 GEMM takes the OCP format only, so
+        torch.float8_e4m3fnuz (the MI300-era flavour the reference also accepts) is refused."""
+        if dtype is not None and dtype != torch.float8_e4m3fn:
+            raise NotImplementedError(f"{dtype}: the gfx950 fp8 GEMM (hipBLASLt behind torch._scaled_mm) takes "
+                                      "torch.float8_e4m3fn (OCP e4m3) only")
+        self.fp8_dtype = dtype
+        self.invalidate_fused()
+        return self
+
+    def _scaled_linear(self, xq, scale_a, w8, bias):
+        """torch._scaled_mm exactly as fp8_linear calls it (:347-354): row-wise scale_a, unit scale_b, bf16 bias."""
+        n = w8.shape[0]
+        key = (n, xq.device)
+        if key not in self._ones:
+            self._ones[key] = torch.ones((1, n), dtype=torch.float32, device=xq.device)
+        return torch._scaled_mm(xq, w8.T, scale_a=scale_a, scale_b=self._ones[key], bias=bias,
+                                out_dtype=torch.bfloat16).unsqueeze(0)
 
     # ------------------------------------------------------------------ hot-loaded LoRA (core/vram/layers.py:417-436)
     def add_hot_lora(self, name, lora_a, lora_b):
@@ -252,14 +290,19 @@ class WanModel(nn.Module):
             blocks, x = [], tea_cache.update(x)
         sharded = shard is not None and shard.world_size > 1
         hot = bool(self.hot_loras)
+        fp8 = self.fp8_dtype
+        ctx8 = hip.fp8_quant_rows(context) if fp8 is not None else None      # the text context is the same for all blocks
         mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
         h = hip.ln_modulate(x, mods[0], 0, 1, eps) if blocks else None
         for i, blk in enumerate(blocks):
             mod = mods[i]
             wqkv, bqkv, wkv_c, bkv_c = blk.fused_weights()
             sa, ca = blk.self_attn, blk.cross_attn
+            if fp8 is not None:
+                w8 = blk.fp8_weights(fp8)
+                lin = lambda t, j, bias, act=None: self._scaled_linear(*hip.fp8_quant_rows(t, act), w8[j], bias)      # noqa: E731
             # --- self attention (reference :139-146)
-            qkv = F.linear(h, wqkv, bqkv)
+            qkv = F.linear(h, wqkv, bqkv) if fp8 is None else lin(h, 0, bqkv)
             if hot:
                 for j, nm in enumerate(("q", "k", "v")):
                     self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
@@ -294,14 +337,18 @@ class WanModel(nn.Module):
                 yield i
                 k, v = pending.wait()
                 a = sa.attn(q, k, v)
-            y = F.linear(a, sa.o.weight, sa.o.bias)
+            y = F.linear(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
             if hot:
                 self._hot(f"blocks.{i}.self_attn.o", a, y)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
             x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
             # --- cross attention (reference :170-185)
-            qc = F.linear(h, ca.q.weight, ca.q.bias)
-            kvc = F.linear(context, wkv_c, bkv_c)
+            if fp8 is None:
+                qc = F.linear(h, ca.q.weight, ca.q.bias)
+                kvc = F.linear(context, wkv_c, bkv_c)
+            else:
+                qc = lin(h, 2, ca.q.bias)
+                kvc = self._scaled_linear(*ctx8, w8[3], bkv_c)
             if hot:
                 self._hot(f"blocks.{i}.cross_attn.q", h, qc)
                 self._hot(f"blocks.{i}.cross_attn.k", context, kvc[..., :c])
@@ -309,20 +356,29 @@ class WanModel(nn.Module):
             qc = hip.rmsnorm_rope(qc, ca.norm_q.weight, nh, eps)
             kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
             ac = ca.attn(qc, kc, kvc[..., c:])
-            y = F.linear(ac, ca.o.weight, ca.o.bias)
+            y = F.linear(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
             if hot:
                 self._hot(f"blocks.{i}.cross_attn.o", ac, y)
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
             x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
             # --- ffn (reference :208-209,228)
-            if hot and f"blocks.{i}.ffn.0" in self.hot_loras:      # the adapter adds to the pre-activation: no epilogue fusion
+            if fp8 is not None:      # ffn.0 -> bf16, GELU(tanh) fused into the quantisation of ffn.2's input
+                pre = lin(h, 5, blk.ffn[0].bias)
+                if hot:
+                    self._hot(f"blocks.{i}.ffn.0", h, pre)
+                y = lin(pre, 6, blk.ffn[2].bias, "gelu_tanh")
+                f = None
+            elif hot and f"blocks.{i}.ffn.0" in self.hot_loras:      # the adapter adds to the pre-activation: no epilogue fusion
                 f = hip.activation(self._hot(f"blocks.{i}.ffn.0", h, F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias)), "gelu_tanh")
             elif self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
                 f = torch._addmm_activation(blk.ffn[0].bias, h[0], blk.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
             else:
                 f = hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
-            y = tuning.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)      # table: better hipBLASLt solution at shard sizes
-            if hot:
+            if fp8 is None:
+                y = tuning.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)      # table: better hipBLASLt solution at shard sizes
+            if hot and f"blocks.{i}.ffn.2" in self.hot_loras:
+                if f is None:
+                    f = hip.activation(pre.clone(), "gelu_tanh")
                 self._hot(f"blocks.{i}.ffn.2", f, y)
             if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
                 x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])

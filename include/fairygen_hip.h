@@ -96,6 +96,14 @@ int fg_copy_groups_bf16(const void* src, int64_t src_group_stride, int64_t src_l
                         void* dst, int64_t dst_group_stride, int64_t dst_ld,
                         int groups, int64_t rows, int cols, fg_stream_t stream);
 
+/* Activation side of the reference's fp8 Linear, AutoWrappedLinear.fp8_linear (core/vram/layers.py:321-357): per row of
+ * x (rows, C; leading dimension ldx) scale[r] = max(bf16(max|x_r| / fp8_max), 1) and out_fp8[r] = e4m3fn(x_r / (scale[r] + 1e-8))
+ * (OCP e4m3, torch.float8_e4m3fn; round to nearest even) — the arguments of the torch._scaled_mm call the reference makes
+ * (row-wise scale_a, unit scale_b, bf16 bias).  act 1 applies GELU(tanh) first (ffn.2's input = nn.GELU(ffn.0(x)), rounded
+ * to bf16 like the module output; optionally also written to act_out (rows, C)), act 0 quantises x as is.  fp8_max = 448. */
+int fg_fp8_quant_rows_bf16(const void* x, int64_t ldx, void* out_fp8, float* scale, void* act_out,
+                           int64_t rows, int C, int act, float fp8_max, fg_stream_t stream);
+
 /* Elementwise activation, out may alias x.  kind 0: SiLU (time_embedding / time_projection,
  * models/wan_video_dit.py:312-318); kind 1: GELU(tanh) (ffn / text_embedding, :208-209,307-311). */
 int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t stream);

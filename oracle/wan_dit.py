@@ -63,7 +63,37 @@ def layer_norm(x, eps, weight=None, bias=None):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+def scaled_mm(a8, b8t, scale_a, scale_b, bias, out_dtype):
+    """What torch._scaled_mm computes (row-wise scales): (a8 @ b8t) in fp32 * scale_a * scale_b + bias -> out_dtype.
+    The CPU backend of this container only takes per-tensor scales, so the op is written out; with unit scales it is
+    checked against the real CPU torch._scaled_mm in tests/test_oracle_golden.py."""
+    return ((a8.float() @ b8t.float()) * scale_a * scale_b + bias.float()).to(out_dtype)
+
+
+def fp8_linear(x, weight, bias, dtype=torch.float8_e4m3fn):
+    """AutoWrappedLinear.fp8_linear, core/vram/layers.py:321-357: per-row dynamic activation scale (only ever scaling
+    DOWN: clamp(min=1)), weights cast to fp8 with unit scale, bf16 bias, row-wise scaled matmul, result in x's dtype.
+    PARITY UNPINNED against an execution of the reference: its torch._scaled_mm call with row-wise scales is rejected by
+    the CPU backend here (ordinary RuntimeError), so there is no golden vector; restated line by line."""
+    origin_dtype, origin_shape = x.dtype, x.shape
+    inp = x.reshape(-1, origin_shape[-1])
+    x_max = torch.max(torch.abs(inp), dim=-1, keepdim=True).values
+    fp8_max = 448.0 / 2.0 if dtype == torch.float8_e4m3fnuz else 448.0
+    scale_a = torch.clamp(x_max / fp8_max, min=1.0).float()
+    scale_b = torch.ones((weight.shape[0], 1))
+    inp = (inp / (scale_a + 1e-8)).to(dtype)
+    out = scaled_mm(inp, weight.to(dtype).T, scale_a, scale_b.T, bias.to(torch.bfloat16), origin_dtype)
+    return out.reshape(origin_shape[:-1] + out.shape[-1:])
+
+
+class Fp8Blocks(dict):
+    """A state dict whose `blocks.*` Linears run as fp8_linear (the build's enable_fp8_linear scope)."""
+    fp8_dtype = torch.float8_e4m3fn
+
+
 def linear(sd, prefix, x):
+    if getattr(sd, "fp8_dtype", None) is not None and prefix.startswith("blocks."):
+        return fp8_linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"], sd.fp8_dtype)
     return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
 
 

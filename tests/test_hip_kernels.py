@@ -142,6 +142,31 @@ def test_ulysses_packing_kernels(hip):
         hip.copy_groups(blocks.view(-1), size * g, g, a.view(-1)[:-8], g, C, P, n, g)
 
 
+@pytest.mark.parametrize("C,act", [(3072, None), (14336, "gelu_tanh"), (256, None), (512, "gelu_tanh")])
+def test_fp8_quant_rows(hip, C, act):
+    """fg_fp8_quant_rows_bf16 == the reference's fp8_linear activation path (core/vram/layers.py:331-342), bit for bit:
+    scale_a = clamp(bf16(max|x| / 448), 1), x / (scale_a + 1e-8) in fp32, RNE cast to torch.float8_e4m3fn."""
+    rows = 37
+    wide = seeded((1, rows, C + 64), 111, scale=2.0)
+    wide[0, 5] *= 400.0                                   # rows above the fp8 range get a scale > 1
+    wide[0, 9] *= 1e-3                                    # and tiny rows exercise the subnormal roundings
+    x = wide[..., 32:32 + C]                              # strided slice (ld = C + 64)
+    xa = F.gelu(x, approximate="tanh") if act else x
+    x2 = xa.reshape(-1, C)
+    want_scale = torch.clamp(x2.abs().amax(-1, keepdim=True) / 448.0, min=1.0).float()
+    want = (x2 / (want_scale + 1e-8)).to(torch.float8_e4m3fn)
+    got, scale = hip.fp8_quant_rows(dev(wide)[..., 32:32 + C], act)
+    assert got.dtype == torch.float8_e4m3fn and got.shape == (rows, C) and scale.shape == (rows, 1)
+    assert torch.equal(scale.cpu(), want_scale)
+    assert want_scale[5].item() > 1.0 and want_scale[0].item() == 1.0
+    same = got.cpu().view(torch.uint8) == want.view(torch.uint8)
+    if act is None:
+        assert same.all(), f"{(~same).sum().item()} fp8 bytes differ"
+    else:       # __expf-based GELU vs libm: rare 1-ulp bf16 flips before the quantisation (same allowance as fg_act_bf16)
+        assert same.float().mean().item() > 0.95
+        assert (got.cpu().float() - want.float()).abs().max().item() <= 0.07 * want.float().abs().max().item()
+
+
 def test_activations_and_cfg_euler(hip):
     x = seeded((3, 1000, 8), 14, scale=3.0)
     assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu", max_mismatch=0.05)          # __expf vs libm: rare 1-ulp flips

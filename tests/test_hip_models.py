@@ -172,6 +172,43 @@ def test_lora_hotload_and_clear(golden):
         one.add_hot_lora("proj", seeded((4, 128), 1), seeded((384, 4), 2))
 
 
+def test_fp8_linear_mode_vs_oracle(tiny_dit):
+    """WanModel.enable_fp8_linear(): the blocks' Linears follow AutoWrappedLinear.fp8_linear (per-row dynamic scale, e4m3
+    weights, row-wise torch._scaled_mm).  Checked against the oracle restatement (parity unpinned, see oracle/wan_dit.py)
+    with the same end-to-end bound as the bf16 path, and against the bf16 model (fp8 must actually change the numbers)."""
+    from fairygen_amd.wan_video import model_fn_wan_video
+    from fairygen_amd.wan_video_dit import WanModel
+    _, sd, cfg = tiny_dit
+    m = WanModel(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(device="cuda", dtype=torch.bfloat16).eval()
+    lat, ctx_p, _, _, ts = _tiny_inputs()
+    args = dict(latents=lat.cuda(), timestep=ts, context=ctx_p.cuda(), fuse_vae_embedding_in_latents=True)
+    with torch.no_grad():
+        out_bf16 = model_fn_wan_video(m, **args)
+        out_fp8 = model_fn_wan_video(m.enable_fp8_linear(torch.float8_e4m3fn), **args)
+        out_back = model_fn_wan_video(m.enable_fp8_linear(None), **args)
+    assert torch.equal(out_back, out_bf16) and not torch.equal(out_fp8, out_bf16)
+    want = wan_dit.model_fn(wan_dit.Fp8Blocks(sd), cfg, lat, ts, ctx_p, True)
+    want_bf16 = wan_dit.model_fn(sd, cfg, lat, ts, ctx_p, True)
+    err, drift = (out_fp8.float().cpu() - want.float()).abs().max().item(), (want.float() - want_bf16.float()).abs().max().item()
+    assert cos(out_fp8, want) > 0.999 and err < 0.5 * drift + 0.05, (err, drift)
+    with pytest.raises(NotImplementedError):
+        m.enable_fp8_linear(torch.float8_e4m3fnuz)
+    # one Linear at full width: product call == the reference's call sequence executed on the device
+    from fairygen_amd import hip as fh
+    x = seeded((1, 160, 3072), 121).cuda()
+    w, b = seeded((1024, 3072), 122, scale=0.02).cuda(), seeded((1024,), 123, scale=0.1).cuda()
+    x2 = x.reshape(-1, 3072)
+    scale_a = torch.clamp(x2.abs().amax(-1, keepdim=True) / 448.0, min=1.0).float()
+    ref = torch._scaled_mm((x2 / (scale_a + 1e-8)).to(torch.float8_e4m3fn), w.to(torch.float8_e4m3fn).T, scale_a=scale_a,
+                           scale_b=torch.ones((1, 1024), device="cuda"), bias=b, out_dtype=torch.bfloat16)
+    got = m._scaled_linear(*fh.fp8_quant_rows(x), w.to(torch.float8_e4m3fn), b)[0]
+    assert torch.equal(got, ref)
+    cpu = wan_dit.fp8_linear(x.cpu(), w.cpu(), b.cpu())[0]
+    assert (got.float().cpu() - cpu.float()).abs().max().item() <= 2.0 ** -7 * cpu.float().abs().max().item()
+
+
 def test_medium_dit_block_stack_vs_oracle():
     """Full-width heads (24 x 128, dim 3072) but 2 layers / small ffn, ragged token count, vs the oracle."""
     from fairygen_amd.wan_video_dit import WanModel
