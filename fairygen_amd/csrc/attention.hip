@@ -154,7 +154,10 @@ struct AttnParams {
     float* ml_part;     // [piece][256][2]   (running max in raw score units, row sum)
 };
 
-template <int WAVES, int QB>
+// SHORT_KV only names the instantiation: launches over <= 1024 keys (cross-attention against the text context) get their own
+// kernel symbol, so a rocprofv3 --stats row averages self-attention launches alone and can be laid next to bench.py's
+// `roofline.avg_launch_ms`.
+template <int WAVES, int QB, bool SHORT_KV = false>
 __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(const AttnParams P) {
     const bf16* __restrict__ q = P.q; const bf16* __restrict__ k = P.k; const bf16* __restrict__ v = P.v;
     bf16* __restrict__ out = P.out;
@@ -780,7 +783,10 @@ extern "C" int fg_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64
 #if FG_ATTN_VARIANT == 4
     hipLaunchKernelGGL((attn_fwd_kernel<4, 1>), dim3((unsigned)(total_direct + pieces)), dim3(256), 0, (hipStream_t)stream, P);
 #else
-    hipLaunchKernelGGL((attn_fwd_kernel<8, 1>), dim3((unsigned)(total_direct + pieces)), dim3(512), 0, (hipStream_t)stream, P);
+    if (Nkv <= 1024)
+        hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((unsigned)(total_direct + pieces)), dim3(512), 0, (hipStream_t)stream, P);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<8, 1, false>), dim3((unsigned)(total_direct + pieces)), dim3(512), 0, (hipStream_t)stream, P);
 #endif
     if (int e = fg_launch_status("fg_attn_fwd_bf16")) return e;
     if (pieces > 0) {
