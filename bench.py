@@ -181,7 +181,6 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=4096)
     ap.add_argument("--skip-vae", action="store_true", help="debug: denoise loop only (reported in config)")
     ap.add_argument("--gelu-epilogue", type=int, default=1, help="0: separate GELU kernel after ffn.0 instead of the GEMM epilogue")
-    ap.add_argument("--cfg-streams", type=int, default=-1, help="1: CFG branches on two HIP streams (experimental; default off)")
     ap.add_argument("--linear-dtype", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: the reference's fp8 Linear mode for the DiT blocks (config 5's weight path); NOT the headline config")
     ap.add_argument("--layout", default=os.environ.get("FAIRYGEN_PARALLEL", "auto"), choices=("auto",) + LAYOUTS,
@@ -208,8 +207,6 @@ def main():
     if world > 1 and args.layout != "auto":
         cfgp, mode = args.layout.split("-")
         pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
-    if args.cfg_streams >= 0:
-        pipe.cfg_streams = bool(args.cfg_streams)
     H, W, F_ = args.height, args.width, args.frames
     lat_shape = (1, 48, (F_ - 1) // 4 + 1, H // 16, W // 16)
     n_tokens = lat_shape[2] * (lat_shape[3] // 2) * (lat_shape[4] // 2)

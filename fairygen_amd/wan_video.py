@@ -265,8 +265,6 @@ class WanVideoPipeline(torch.nn.Module):
         self.model_fn = model_fn_wan_video
         self.sequence_shard = None          # set by enable_sequence_parallel(): token shard group of this rank
         self.parallel = None                # sequence_parallel.ParallelLayout (world = cfg_parallel x sp)
-        self.cfg_streams = False            # True: issue the two CFG branches on two HIP streams (experimental)
-        self._cfg_side_streams = None
         self.use_unified_sequence_parallel = False
 
     # ----------------------------------------------------------------------------- construction
@@ -439,27 +437,21 @@ class WanVideoPipeline(torch.nn.Module):
 
     def denoise(self, inputs_shared, inputs_posi, inputs_nega, cfg_scale, progress_bar_cmd=tqdm):
         """The hot loop: per step forward(+), forward(-), then CFG combine + Euler step fused in one HIP kernel,
-        then the first latent frame re-pinned (TI2V).
+        then the first latent frame re-pinned (TI2V).  How the two forwards of a step are issued depends on the layout:
 
-        With `cfg_streams=True` (opt-in, off by default) the two CFG branches — which
-        are independent until the combine — are issued on two HIP streams: one branch's K/V all-gather over xGMI then
-        runs under the other branch's GEMMs / attention instead of stalling the device.  Collectives are still issued
-        in the same program order on every rank."""
+        * single GPU: one after the other;
+        * cfg_parallel = 2: this rank's half of the world computes ONE branch, one world all-gather exchanges the predictions;
+        * token-sharded, cfg_parallel = 1: the two branches — independent until the combine — are advanced in lockstep on
+          ONE stream, each yielding right after it has started an exchange: branch B's GEMMs run while A's tensors cross
+          xGMI, A's attention / FFN while B's do.  Collectives keep one program order on every rank."""
         models = {name: getattr(self, name) for name in self.in_iteration_models}
         shared = {k: v for k, v in inputs_shared.items() if k in ("latents", "fuse_vae_embedding_in_latents")}
         shared["sequence_shard"] = self.sequence_shard
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
-        two_streams = bool(self.cfg_streams) and cfg_scale != 1.0 and latents.is_cuda
-        # Token-sharded runs: the two CFG branches are independent until the combine, so they are advanced in lockstep
-        # on ONE stream, each yielding right after it has started its K/V all-gather: branch B's GEMMs run while A's
-        # K/V cross xGMI, A's attention / FFN while B's do.  Collectives keep one program order on every rank.
         sharded = self.sequence_shard is not None and self.sequence_shard.world_size > 1
-        interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not two_streams
-        if two_streams and self._cfg_side_streams is None:
-            self._cfg_side_streams = (torch.cuda.Stream(latents.device), torch.cuda.Stream(latents.device))
         cfg_split = self.parallel is not None and self.parallel.cfg_parallel == 2 and self.model_fn is model_fn_wan_video
-        interleave = interleave and not cfg_split
+        interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
@@ -470,18 +462,6 @@ class WanVideoPipeline(torch.nn.Module):
                 both = self.parallel.gather_branches(out_loc, grid[0] * grid[1] * grid[2])
                 posi = self.dit.unpatchify(both[0:1], grid).contiguous()
                 nega = self.dit.unpatchify(both[1:2], grid).contiguous() if cfg_scale != 1.0 else None
-            elif two_streams:
-                main = torch.cuda.current_stream(latents.device)
-                outs = []
-                for side, ctx in zip(self._cfg_side_streams, (inputs_posi, inputs_nega)):
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        o = self.model_fn(**models, **shared, **inputs_posi_ctx(ctx), timestep=ts).contiguous()
-                    o.record_stream(main)
-                    outs.append(o)
-                for side in self._cfg_side_streams:
-                    main.wait_stream(side)
-                posi, nega = outs
             elif interleave:
                 gens = [model_fn_wan_video_steps(**models, **shared, **inputs_posi_ctx(c), timestep=ts)
                         for c in (inputs_posi, inputs_nega)]

@@ -73,13 +73,6 @@ def test_tiny_denoise_loop_vs_golden(tiny_dit, golden):
     want = g["loop_step3"]
     assert cos(out, want) > 0.999
     assert torch.equal(out[:, :, 0:1].cpu(), z0)
-    # the two CFG branches on two HIP streams (the multi-GPU overlap mode) must give the same latents
-    pipe.cfg_streams = True
-    shared["latents"] = latents.cuda()
-    with torch.no_grad():
-        out2 = pipe.denoise(shared, {"context": ctx_p.cuda()}, {"context": ctx_n.cuda()}, 5.0, progress_bar_cmd=lambda x: x)
-    torch.cuda.synchronize()
-    assert torch.equal(out2, out)
 
 
 def test_teacache_loop_vs_golden(tiny_dit, golden):
