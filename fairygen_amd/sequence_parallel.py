@@ -248,19 +248,33 @@ class ParallelLayout:
     whole world.  cfg_parallel = 2: ranks [0, W/2) run the positive branch, [W/2, W) the negative one, each half
     sequence-parallel over its own group; one world all-gather per step exchanges the predictions."""
 
-    def __init__(self, cfg_parallel=1, attn_mode="allgather"):
-        self.world = TokenShard(None, attn_mode)
-        w = self.world.world_size
+    def __init__(self, cfg_parallel=1, attn_mode="allgather", ranks=None):
+        """ranks: the global ranks that work on ONE clip together (default: every rank of the default group).  Several
+        disjoint rank sets = replicas serving different clips (replica_ranks()); every process must construct the layouts
+        of ALL replicas in the same order (process-group creation is collective), see fairygen_amd.batch."""
+        initialised = dist.is_available() and dist.is_initialized()
+        everyone = list(range(dist.get_world_size())) if initialised else [0]
+        ranks = everyone if ranks is None else list(ranks)
+        member = (dist.get_rank() if initialised else 0) in ranks
+        base = None if ranks == everyone else _subgroup(ranks)
+        w = len(ranks)
         if cfg_parallel not in (1, 2) or w % cfg_parallel != 0:
-            raise ValueError(f"cfg_parallel must be 1 or 2 and divide the world size {w}, got {cfg_parallel}")
-        self.cfg_parallel, self.attn_mode = cfg_parallel, attn_mode
-        if cfg_parallel == 1 or w == 1:
-            self.cfg_parallel, self.branch, self.shard = 1, None, self.world
-        else:
+            raise ValueError(f"cfg_parallel must be 1 or 2 and divide the group size {w}, got {cfg_parallel}")
+        self.ranks, self.member = ranks, member
+        self.cfg_parallel, self.attn_mode = (cfg_parallel if w > 1 else 1), attn_mode
+        halves = None
+        if self.cfg_parallel == 2:
             sp = w // 2
-            groups = [_subgroup(range(b * sp, (b + 1) * sp)) for b in range(2)]      # both created on every rank
-            self.branch = self.world.rank // sp
-            self.shard = TokenShard(groups[self.branch], attn_mode)
+            halves = [_subgroup(ranks[b * sp:(b + 1) * sp]) for b in range(2)]        # both created on every process
+        if not member:            # this process only took part in creating the groups
+            self.world = self.shard = self.branch = None
+            return
+        self.world = TokenShard(base, attn_mode)
+        if self.cfg_parallel == 1:
+            self.branch, self.shard = None, self.world
+        else:
+            self.branch = self.world.rank // (w // 2)
+            self.shard = TokenShard(halves[self.branch], attn_mode)
 
     @property
     def sp(self):
@@ -277,6 +291,13 @@ class ParallelLayout:
         size = self.shard.chunk(n)
         full = self.world._gather_rows(out_local[0], size)                      # (2*sp*size, C), branch-major
         return full.view(2, self.sp * size, -1)[:, :n]
+
+
+def replica_ranks(world_size, replica_size):
+    """Disjoint, contiguous rank sets of `replica_size` GPUs each (one clip per set at a time): [[0,1],[2,3],...]."""
+    if replica_size < 1 or world_size % replica_size != 0:
+        raise ValueError(f"replica_size {replica_size} must divide the world size {world_size}")
+    return [list(range(r, r + replica_size)) for r in range(0, world_size, replica_size)]
 
 
 def assign_tiles(costs, world):

@@ -309,12 +309,13 @@ class WanVideoPipeline(torch.nn.Module):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         return self.dit.num_heads % world == 0
 
-    def enable_sequence_parallel(self, cfg_parallel=1, attn_mode="allgather"):
+    def enable_sequence_parallel(self, cfg_parallel=1, attn_mode="allgather", layout=None):
         """Shard the denoise loop over the default process group: world = cfg_parallel x sp.  cfg_parallel = 2 gives
         each half of the ranks one CFG branch; inside a half (or the whole world) tokens are sharded by
-        latent-temporal ranges and self-attention exchanges by `attn_mode` ("allgather" K/V or "ulysses")."""
+        latent-temporal ranges and self-attention exchanges by `attn_mode` ("allgather" K/V or "ulysses").
+        layout: a ready sequence_parallel.ParallelLayout (e.g. one replica's, fairygen_amd.batch) instead."""
         from .sequence_parallel import ParallelLayout
-        self.parallel = ParallelLayout(cfg_parallel, attn_mode)
+        self.parallel = layout if layout is not None else ParallelLayout(cfg_parallel, attn_mode)
         self.sequence_shard = self.parallel.shard
         self.use_unified_sequence_parallel = True
         return self

@@ -127,6 +127,52 @@ def test_cfg_parallel_layout_gloo(tmp_path, world, port):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
+def _replica_worker(rank, world, port, result_dir):
+    """Multi-shot serving: disjoint replicas (2 ranks per clip, one CFG branch each); collectives never cross replicas."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd.batch import ShotScheduler
+        sched = ShotScheduler(replica_size=2)
+        assert sched.replicas == [[0, 1], [2, 3]] and sched.replica_id == rank // 2 and sched.is_writer == (rank % 2 == 0)
+        lay = sched.layout
+        assert (lay.cfg_parallel, lay.sp, lay.branch, lay.world.world_size, lay.world.rank) == (2, 1, rank % 2, 2, rank % 2)
+        shots = [f"s{i}" for i in range(5)]
+        assert sched.my_shots(shots) == shots[sched.replica_id::2]
+        n, c = 9, 4
+        mine = seeded((1, n, c), 100 + rank)                     # each rank's "prediction" (sp = 1: all tokens)
+        both = lay.gather_branches(mine, n)                      # exchanged inside the replica only
+        r0 = 2 * sched.replica_id
+        assert torch.equal(both[0], seeded((1, n, c), 100 + r0)[0]) and torch.equal(both[1], seeded((1, n, c), 101 + r0)[0])
+        tile = seeded((2, 3), 200 + rank)
+        lay.world.broadcast(tile, src=1)                         # replica-local rank 1 = global rank r0 + 1
+        assert torch.equal(tile, seeded((2, 3), 201 + r0))
+        one = ShotScheduler(replica_size=4, cfg_parallel=1, attn_mode="allgather")
+        assert one.n_replicas == 1 and one.layout.sp == 4 and one.layout.world.group is None
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shot_scheduler_replicas_gloo(tmp_path):
+    mp.spawn(_replica_worker, args=(4, 29639, str(tmp_path)), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(4))
+
+
+def test_list_shots_and_single_process_scheduler(tmp_path):
+    from fairygen_amd.batch import ShotScheduler, list_shots
+    from fairygen_amd.sequence_parallel import replica_ranks
+    for name in ("2.png", "10.png", "1.png", "1.txt", "10.txt", "notes.md"):
+        (tmp_path / name).write_text("a pig walks")
+    shots = list_shots(str(tmp_path))                            # "2.png" has no prompt: skipped, like the reference
+    assert [s[0] for s in shots] == ["1", "10"]
+    sched = ShotScheduler(replica_size=2)                        # no process group: one replica of one rank
+    assert sched.n_replicas == 1 and sched.layout is None and sched.is_writer and sched.my_shots(shots) == shots
+    assert replica_ranks(8, 2) == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    with pytest.raises(ValueError):
+        replica_ranks(8, 3)
+
+
 def test_assign_tiles_balances_by_area():
     from fairygen_amd.sequence_parallel import assign_tiles
     from fairygen_amd.wan_video_vae import WanVideoVAE38
@@ -200,6 +246,50 @@ def _gpu_worker(rank, world, port, result_dir):
         open(os.path.join(result_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_replica_worker(rank, world, port, result_dir):
+    """4 gloo ranks on the one test GPU = 2 replicas x (one CFG branch per rank): each replica denoises its own clip
+    (different seed) and must reproduce the single-process result of that clip."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd import synthetic
+        from fairygen_amd.batch import ShotScheduler
+        from fairygen_amd.wan_video import WanVideoPipeline
+        from fairygen_amd.wan_video_dit import WanModel
+        cfg = dict(synthetic.TINY_DIT_KWARGS, dim=512, num_heads=4, ffn_dim=1024)
+        m = WanModel(**cfg)
+        m.load_state_dict(synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=77))
+        m = m.to(device="cuda", dtype=torch.bfloat16).eval()
+        sched = ShotScheduler(replica_size=2)
+        clip_seed = 300 + sched.replica_id
+        lat, z0 = seeded((1, 48, 3, 10, 14), clip_seed).cuda(), seeded((1, 48, 1, 10, 14), 8).cuda()
+        ctx, ctx_n = seeded((1, 24, 128), 6).cuda(), seeded((1, 24, 128), 7).cuda()
+        outs = []
+        for replicated in (False, True):
+            pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+            pipe.dit = m
+            if replicated:
+                sched.attach(pipe)
+                assert pipe.parallel.describe() == "cfg2xsp1"
+            pipe.scheduler.set_timesteps(3, denoising_strength=1.0, shift=5.0)
+            lat0 = lat.clone()
+            lat0[:, :, 0:1] = z0
+            shared = {"latents": lat0, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0}
+            with torch.no_grad():
+                outs.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), "a replica's clip must equal the single-process clip bit for bit"
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replicas_on_gpu(tmp_path):
+    mp.spawn(_gpu_replica_worker, args=(4, 29643, str(tmp_path)), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(4))
 
 
 @pytest.mark.gpu
