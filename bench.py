@@ -240,7 +240,7 @@ def main():
     autotune = None
     with torch.no_grad():
         if world > 1 and args.layout == "auto":
-            # untimed: one warm step + one timed step of every candidate layout at full shape; all ranks agree on the
+            # untimed: one warm step + two timed steps of every candidate layout at full shape; all ranks agree on the
             # fastest through a MAX all-reduce of their times
             autotune = {}
             for cfgp, mode in candidate_layouts(world, cfg["num_heads"]):
@@ -249,9 +249,9 @@ def main():
                 torch.cuda.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
-                run_clip(1, decode=False)
+                run_clip(2, decode=False)
                 torch.cuda.synchronize()
-                autotune[f"cfg{cfgp}-{mode}"] = round(sync_max(time.perf_counter() - t0) * 1e3, 2)
+                autotune[f"cfg{cfgp}-{mode}"] = round(sync_max(time.perf_counter() - t0) / 2 * 1e3, 2)
             best = min(autotune, key=autotune.get)
             cfgp, mode = best.split("-")
             pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
