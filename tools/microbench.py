@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--ks", type=int, default=3)
     ap.add_argument("--rows", type=int, default=27280)
     ap.add_argument("--interleaved", action="store_true")
+    ap.add_argument("--per-head", action="store_true")
     a = ap.parse_args()
     hip.load()
     dev = "cuda"
@@ -57,6 +58,13 @@ def main():
             q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
         else:
             q, k, v = rnd(1, a.nq, c), rnd(1, a.nkv, c), rnd(1, a.nkv, c)
+        if a.per_head:         # (H, N, 128): every head's rows contiguous (row stride 256 B instead of H*256 B)
+            q, k, v = (t.view(a.nq if t is q else a.nkv, a.heads, 128).permute(1, 0, 2).contiguous() for t in (q, k, v))
+            out = torch.empty((a.heads, a.nq, 128), dtype=torch.bfloat16, device=dev)
+            med, mn = timeit(lambda: hip.attention(q, k, v, 1, out=out), a.iters)
+            fl = 4.0 * a.nq * a.nkv * c
+            print(f"attn per-head layout nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
+            return
         out = torch.empty((1, a.nq, c), dtype=torch.bfloat16, device=dev)
         med, mn = timeit(lambda: hip.attention(q, k, v, a.heads, out=out), a.iters)
         fl = 4.0 * a.nq * a.nkv * c
