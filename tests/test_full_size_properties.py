@@ -47,6 +47,33 @@ def test_attention_full_size_sampled_rows_and_properties(hip):
     assert (os_ - out[:, lo:hi].float()).abs().max().item() < 4e-3
 
 
+def test_attention_head_shard_equals_full_call(hip):
+    """The Ulysses head shard at P = 8 (3 of 24 heads over ALL 27 280 tokens, q | k | v as column slices of one
+    (N, 1152) buffer, i.e. what the all-to-all delivers) gives the same numbers as those heads' columns of the full call."""
+    q, k, v = _rand((1, N, H * D), 11), _rand((1, N, H * D), 12), _rand((1, N, H * D), 13)
+    full = hip.attention(q, k, v, H)
+    g = 3 * D
+    for rank in (0, 5):
+        cols = slice(rank * g, (rank + 1) * g)
+        buf = torch.cat([q[..., cols], k[..., cols], v[..., cols]], dim=-1).contiguous()      # (1, N, 1152)
+        part = hip.attention(buf[..., :g], buf[..., g:2 * g], buf[..., 2 * g:], 3)
+        assert (part.float() - full[..., cols].float()).abs().max().item() < 4e-3
+
+
+def test_fp8_quant_full_size_round_trip(hip):
+    """fg_fp8_quant_rows_bf16 on the full ffn.2 input (27 280 x 14 336): scale >= 1, |q| <= 448, and q * scale recovers x to
+    e4m3 precision (relative 2^-4 per element above the subnormal range)."""
+    x = _rand((1, N, 14336), 14, scale=3.0)
+    x[0, 7] *= 200.0
+    q8, scale = hip.fp8_quant_rows(x)
+    assert q8.shape == (N, 14336) and scale.shape == (N, 1) and scale.min().item() == 1.0 and scale[7].item() > 1.0
+    deq = q8.float() * (scale + 1e-8)
+    xf = x[0].float()
+    assert q8.float().abs().max().item() <= 448.0
+    err = (deq - xf).abs()
+    assert bool((err <= 2.0 ** -4 * xf.abs() + 2.0 ** -9 * scale).all())
+
+
 @pytest.mark.parametrize("cin,cout,T,Hh,Ww", [(256, 256, 4, 240, 416), (1024, 1024, 2, 60, 104)])
 def test_conv_full_size_sampled_pixels(hip, cin, cout, T, Hh, Ww):
     """A last-stage and a second-stage decoder layer of a 480x832 tile (256x256 LDS-DMA tile variant), checked on sampled
