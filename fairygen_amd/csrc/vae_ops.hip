@@ -6,32 +6,37 @@ namespace {
 
 constexpr int kMaxVecV = 4;   // C <= 2048 per pixel row, one wave per pixel
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // F.normalize(x, dim=C) * sqrt(C) * gamma (+ SiLU): every op rounded to bf16 like the reference chain.
+// LPP lanes own one pixel (64: C <= 2048; 32: C <= 256, two pixels per wave so that no lane idles on the 256-channel
+// last stage, where this kernel is VALU-bound: ~35 VALU ops per element for the divisions, roundings and SiLU).
+template <int LPP>
 __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                           bf16* __restrict__ out, int64_t pixels, int C, float sqrt_c,
                                                           int apply_silu) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= pixels) return;
+    constexpr int kPerWave = 64 / LPP, kVec = LPP == 64 ? kMaxVecV : 1;
+    const int lane = threadIdx.x & (LPP - 1);
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kPerWave + ((threadIdx.x & 63) / LPP);
+    const bool live = row < pixels;          // both halves of a wave take part in the shuffles
     const int nvec = C >> 3;
-    float v[kMaxVecV][8];
+    float v[kVec][8];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVecV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) {
+    for (int i = 0; i < kVec; ++i) {
+        const int vi = lane + i * LPP;
+        if (live && vi < nvec) {
             const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + row * C + (int64_t)vi * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[i][j] = (float)t[j]; ss += v[i][j] * v[i][j]; }
         }
     }
-    ss = wave_sum(ss);
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (!live) return;
     const float denom = fmaxf(rbf(sqrtf(ss)), 1e-12f);
 #pragma unroll
-    for (int i = 0; i < kMaxVecV; ++i) {
-        const int vi = lane + i * 64;
+    for (int i = 0; i < kVec; ++i) {
+        const int vi = lane + i * LPP;
         if (vi < nvec) {
             const bf16x8 g = *reinterpret_cast<const bf16x8*>(gamma + (int64_t)vi * 8);
             bf16x8 o;
@@ -250,8 +255,12 @@ int fg_vae_rmsnorm_silu_bf16(const void* x, const void* gamma, void* out, int64_
                  kMaxVecV * 512);
     FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(gamma) && FG_ALIGNED16(out), "fg_vae_rmsnorm_silu_bf16: misaligned pointer");
     if (pixels == 0) return FG_OK;
-    hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)((pixels + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sqrtf((float)C), apply_silu);
+    if (C <= 256)
+        hipLaunchKernelGGL(vae_rmsnorm_kernel<32>, dim3((unsigned)((pixels + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sqrtf((float)C), apply_silu);
+    else
+        hipLaunchKernelGGL(vae_rmsnorm_kernel<64>, dim3((unsigned)((pixels + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sqrtf((float)C), apply_silu);
     return fg_launch_status("fg_vae_rmsnorm_silu_bf16");
 }
 
