@@ -484,6 +484,10 @@ __global__ __launch_bounds__(WAVES * 64, QB == 1 ? 2 : 1) void attn_fwd_kernel(c
     m_run[0] = tile_max(sA);
     __syncthreads();      // every wave is done with the first K tile before step 0 overwrites it
 
+#ifdef FG_YOUNG_PRIO
+    // static priority for the second-dispatched half of the workgroup (the arbitration loser at equal priority)
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(FG_YOUNG_PRIO);
+#endif
     // fast steps: the next tile exists in this range and is full
     const int t_fast = min(t_end - 1, (int)(Nkv / kBN) - 1);
     int t = t_begin;
