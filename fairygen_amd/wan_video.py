@@ -182,13 +182,20 @@ class WanVideoUnit_PromptEmbedder(PipelineUnit):
 
 
 class WanVideoUnit_InputVideoEmbedder(PipelineUnit):
-    def __init__(self):
-        super().__init__(input_params=("input_video", "noise"), output_params=("latents",))
+    """:366-390 — text-to-video starts from the noise; video-to-video (`input_video=` frames + `denoising_strength`)
+    from the VAE38-encoded video noised to the first timestep of the shortened schedule."""
 
-    def process(self, pipe, input_video, noise):
-        if input_video is not None:
-            raise NotImplementedError("video-to-video (multi-frame VAE encode) is not on the FairyGen inference path")
-        return {"latents": noise}
+    def __init__(self):
+        super().__init__(input_params=("input_video", "noise", "tiled", "tile_size", "tile_stride"),
+                         output_params=("latents", "input_latents"), onload_model_names=("vae",))
+
+    def process(self, pipe, input_video, noise, tiled, tile_size, tile_stride):
+        if input_video is None:
+            return {"latents": noise}
+        video = pipe.preprocess_video(input_video)
+        input_latents = pipe.vae.encode(video, device=pipe.device, tiled=tiled, tile_size=tile_size,
+                                        tile_stride=tile_stride).to(dtype=pipe.torch_dtype, device=pipe.device)
+        return {"latents": pipe.scheduler.add_noise(input_latents, noise, timestep=pipe.scheduler.timesteps[0])}
 
 
 class WanVideoUnit_ImageEmbedderFused(PipelineUnit):
@@ -230,7 +237,7 @@ class WanVideoUnit_TeaCache(PipelineUnit):
 
 
 _OUT_OF_SCOPE_KWARGS = (
-    "end_image", "input_video", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
+    "end_image", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
     "control_video", "reference_image", "camera_control_direction", "vace_video", "vace_video_mask",
     "vace_reference_image", "animate_pose_video", "animate_face_video", "animate_inpaint_video", "animate_mask_video",
     "vap_video", "motion_bucket_id", "longcat_video", "sliding_window_size", "sliding_window_stride",
@@ -343,6 +350,12 @@ class WanVideoPipeline(torch.nn.Module):
         x = x * ((max_value - min_value) / 255) + min_value
         return x.permute(2, 0, 1).unsqueeze(0)
 
+    def preprocess_video(self, video, torch_dtype=None, device=None, pattern="B C T H W", min_value=-1, max_value=1):
+        """list of PIL frames -> (1,C,T,H,W) in [min,max] (base_pipeline.py:121-125)."""
+        frames = [self.preprocess_image(im, torch_dtype=torch_dtype, device=device, min_value=min_value, max_value=max_value)
+                  for im in video]
+        return torch.stack(frames, dim=pattern.index("T") // 2)
+
     def generate_noise(self, shape, seed=None, rand_device="cpu", rand_torch_dtype=torch.float32, device=None, torch_dtype=None):
         generator = None if seed is None else torch.Generator(rand_device).manual_seed(seed)
         noise = torch.randn(shape, generator=generator, device=rand_device, dtype=rand_torch_dtype)
@@ -391,7 +404,7 @@ class WanVideoPipeline(torch.nn.Module):
 
     # ----------------------------------------------------------------------------- __call__
     @torch.no_grad()
-    def __call__(self, prompt, negative_prompt="", input_image=None, seed=None, rand_device="cpu", height=480, width=832,
+    def __call__(self, prompt, negative_prompt="", input_image=None, input_video=None, seed=None, rand_device="cpu", height=480, width=832,
                  num_frames=81, cfg_scale=5.0, cfg_merge=False, switch_DiT_boundary=0.875, num_inference_steps=50,
                  sigma_shift=5.0, denoising_strength=1.0, tiled=True, tile_size=(30, 52), tile_stride=(15, 26),
                  tea_cache_l1_thresh=None, tea_cache_model_id="", progress_bar_cmd=tqdm, output_type="quantized",
@@ -410,7 +423,7 @@ class WanVideoPipeline(torch.nn.Module):
         inputs_posi = {"prompt": prompt, **tea}
         inputs_nega = {"negative_prompt": negative_prompt, **tea}
         inputs_shared = {
-            "input_image": input_image, "first_frame_latents": first_frame_latents, "input_video": None,
+            "input_image": input_image, "first_frame_latents": first_frame_latents, "input_video": input_video,
             "seed": seed, "rand_device": rand_device, "height": height, "width": width, "num_frames": num_frames,
             "cfg_scale": cfg_scale, "cfg_merge": cfg_merge, "sigma_shift": sigma_shift,
             "tiled": tiled, "tile_size": tile_size, "tile_stride": tile_stride,

@@ -195,6 +195,7 @@ class VideoVAE38_(nn.Module):
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d_38(dec_dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
         self._conv_states = None
+        self._down_cache = {}
         self.z_dim = z_dim
         self.max_chunk_group = 4      # latent frames per decoder call after the first (1 = the reference's chunking)
 
@@ -293,6 +294,7 @@ class VideoVAE38_(nn.Module):
         return self._cconv(dec.head[2], x.shape[0])
 
     def clear_cache(self):
+        self._down_cache = {}
         if self._conv_states is not None:
             for st in self._conv_states.values():
                 st.ring = None
@@ -324,36 +326,52 @@ class VideoVAE38_(nn.Module):
         self.clear_cache()
         return video.unsqueeze(0)
 
-    def _resample_down(self, rs, x):
+    def _resample_down(self, rs, x, first_chunk):
+        """Resample.forward, downsample modes (reference :155-174): strided 3x3 Conv2d per frame, then for 'downsample3d' the
+        temporal stride-2 time_conv over [last frame of the previous chunk; chunk].  The first chunk only leaves its frame
+        behind as that cache and skips time_conv (:163-165)."""
         x = self._conv(rs.resample[1], x, downsample2x=True)
-        # downsample3d on the first chunk only stores its cache and skips time_conv (reference :163-167)
+        if rs.mode == "downsample3d":
+            key = id(rs)
+            if first_chunk:
+                self._down_cache[key] = x[-1:].clone()
+            else:
+                seq = torch.cat([self._down_cache[key], x], 0)            # (t+1, h, w, c); kernel (3,1,1), no padding
+                self._down_cache[key] = x[-1:].clone()
+                x = self._conv(rs.time_conv, seq)[::2].contiguous()        # stride 2 in time = every other stride-1 output
         return x
 
-    def encode(self, x, scale):
-        """First-frame conditioning: x (1,3,1,H,W) in [-1,1] on the HIP device -> mu (1,48,1,H/16,W/16), normalised
-        (reference :1298-1323 with t == 1: a single encoder chunk, no temporal down-convolution)."""
-        assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3
-        if x.shape[2] != 1:
-            raise NotImplementedError("multi-frame (video-to-video) encode is not on the FairyGen inference path")
-        self._states(encoder=True)
-        self.clear_cache()
+    def _encoder_chunk(self, y, first_chunk):
+        """One Encoder3d_38 pass (reference :673-733) over a chunk of patchified frames (1 frame first, then 4)."""
         enc = self.encoder
-        mean, inv_std = (s.to(dtype=x.dtype, device=x.device).contiguous() for s in scale)
-        y = hip.vae_patchify(x[0].contiguous())
         self._slot(enc.conv1, y).copy_(y)
-        y = self._cconv(enc.conv1, 1)
+        y = self._cconv(enc.conv1, y.shape[0])
         for blk in enc.downsamples:
             y_copy = y
             for layer in blk.downsamples:
-                y = self._res(layer, y) if isinstance(layer, ResidualBlock) else self._resample_down(layer, y)
+                y = self._res(layer, y) if isinstance(layer, ResidualBlock) else self._resample_down(layer, y, first_chunk)
             sc = blk.avg_shortcut
             y = hip.avgdown3d_add(y_copy, y, sc.factor_t, sc.factor_s)
         y = self._res(enc.middle[0], y)
         y = self._attn(enc.middle[1], y)
         y = self._res(enc.middle[2], y)
         hip.vae_rmsnorm_silu(y, enc.head[0].gamma.view(-1), True, out=self._slot(enc.head[2], y))
-        y = self._cconv(enc.head[2], 1)
-        y = self._conv(self.conv1, y)
+        return self._cconv(enc.head[2], y.shape[0])
+
+    def encode(self, x, scale):
+        """x (1,3,T,H,W) in [-1,1] on the HIP device -> mu (1,48,1+(T-1)//4,H/16,W/16), normalised (reference :1298-1323):
+        the first frame alone, then chunks of 4 frames through the encoder with its causal feature caches.  T = 1 is the
+        TI2V first-frame conditioning of the FairyGen path; T > 1 is the video-to-video input."""
+        assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3
+        self._states(encoder=True)
+        self.clear_cache()
+        mean, inv_std = (s.to(dtype=x.dtype, device=x.device).contiguous() for s in scale)
+        frames = hip.vae_patchify(x[0].contiguous())
+        outs = []
+        for i in range(1 + (x.shape[2] - 1) // 4):
+            chunk = frames[:1] if i == 0 else frames[1 + 4 * (i - 1):1 + 4 * i]
+            outs.append(self._encoder_chunk(chunk, first_chunk=(i == 0)))
+        y = self._conv(self.conv1, outs[0] if len(outs) == 1 else torch.cat(outs, 0))
         mu = hip.vae_latent_from_cl(y, mean, inv_std, self.z_dim)
         self.clear_cache()
         return mu.unsqueeze(0)

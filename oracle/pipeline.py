@@ -32,14 +32,14 @@ def generate_noise(shape, seed, dtype=torch.bfloat16):
 
 def denoise_loop(sd, cfg, latents, context_posi, context_nega, num_inference_steps, cfg_scale=5.0,
                  sigma_shift=5.0, first_frame_latents=None, dtype=torch.bfloat16, record=None, num_blocks=None,
-                 tea_cache_l1_thresh=None, tea_cache_model_id=""):
+                 tea_cache_l1_thresh=None, tea_cache_model_id="", denoising_strength=1.0):
     """wan_video.py:283-309 — per step: forward+, forward-, CFG combine, Euler step, re-pin frame 0.
     tea_cache_l1_thresh: one TeaCache per CFG branch (WanVideoUnit_TeaCache, :769-781)."""
     tea_p = tea_n = None
     if tea_cache_l1_thresh is not None:
         tea_p = wan_dit.TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id)
         tea_n = wan_dit.TeaCache(num_inference_steps, tea_cache_l1_thresh, tea_cache_model_id)
-    sigmas, timesteps = wan_sigmas(num_inference_steps, shift=sigma_shift)
+    sigmas, timesteps = wan_sigmas(num_inference_steps, denoising_strength, shift=sigma_shift)
     fuse = first_frame_latents is not None
     if fuse:
         latents = latents.clone()
@@ -58,6 +58,11 @@ def denoise_loop(sd, cfg, latents, context_posi, context_nega, num_inference_ste
         if record is not None:
             record.append(latents.clone())
     return latents
+
+
+def add_noise(original_samples, noise, sigma):
+    """flow_match.py:164-170 — (1 - sigma) x0 + sigma eps at the schedule's first sigma (video-to-video start)."""
+    return (1 - sigma) * original_samples + sigma * noise
 
 
 def video_to_uint8(video):

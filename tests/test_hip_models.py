@@ -271,8 +271,16 @@ def test_tiny_vae_encode_vs_golden(tiny_vae, golden):
     assert err <= 2 * err_ref + 2e-2, (err, err_ref)
     assert cos(z, g["encode_image_bf16"]) > 0.9995 and cos(zt, g["encode_image_tiled_bf16"]) > 0.9995
     assert (zt.float().cpu() - g["encode_image_tiled_bf16"].float()).abs().max().item() <= 2 * err_ref + 4e-2
-    with pytest.raises(NotImplementedError):
-        vae.encode([seeded((3, 5, 64, 96), 1).cuda()], device="cuda")
+    # multi-frame input (video-to-video): 9 frames = the first frame + two 4-frame chunks through the temporal
+    # down-convolutions and their caches -> 3 latent frames, against the reference's own chunked encode
+    vid = seeded((3, 9, 64, 96), 33, scale=0.5).clamp(-1, 1)
+    with torch.no_grad():
+        zv = vae.encode([vid.cuda()], device="cuda")
+        z1 = vae.encode([vid[:, :1].contiguous().cuda()], device="cuda")
+    want = g["encode_video_bf16"]
+    assert zv.shape == want.shape == (1, 48, 3, 4, 6)
+    assert cos(zv, want) > 0.9995 and (zv.float().cpu() - want.float()).abs().max().item() <= 2 * err_ref + 4e-2
+    assert torch.equal(zv[:, :, :1], z1), "the first latent frame depends on the first video frame only (causal encoder)"
 
 
 def test_fullwidth_vae_decoder_small_latent_vs_oracle():
@@ -346,6 +354,18 @@ def test_pipeline_call_end_to_end(tmp_path, tiny_vae):
     got2 = np.stack([np.array(f) for f in frames2]).astype("int32")
     want2 = opipe.video_to_uint8(vid2[0]).numpy().astype("int32")
     assert np.abs(got2 - want2).mean() <= 1.5, np.abs(got2 - want2).mean()
+    # video-to-video: input_video= (9 PIL frames) + denoising_strength -> chunked VAE38 encode, noised start, shortened schedule
+    vid_in = [Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)) for _ in range(9)]
+    out3 = pipe(prompt=ctx_p, negative_prompt=ctx_n, input_video=vid_in, denoising_strength=0.6, seed=1, height=64, width=64,
+                num_frames=9, num_inference_steps=2, tiled=False, output_type="floatpoint", progress_bar_cmd=lambda x: x)
+    vid_t = torch.stack([torch.Tensor(np.array(f, dtype=np.float32)).to(torch.bfloat16) * (2 / 255) - 1 for f in vid_in], 0)
+    z_vid = wan_vae.vae_encode(vsd_p, [vid_t.permute(3, 0, 1, 2)])                                       # (1,48,3,4,4)
+    sig, _ = opipe.wan_sigmas(2, 0.6, 5.0)
+    start = opipe.add_noise(z_vid, noise, sig[0])
+    lat3 = opipe.denoise_loop(dsd, cfg, start, ctx_p, ctx_n, 2, 5.0, 5.0, None, denoising_strength=0.6)
+    want3 = wan_vae.vae_decode(vsd_p, lat3, False)
+    assert out3.shape == want3.shape == (1, 3, 9, 64, 64)
+    assert (out3.float().cpu() - want3.float()).abs().mean().item() < 0.02 and cos(out3, want3) > 0.99
 
 
 def _tiny_text_encoder():
