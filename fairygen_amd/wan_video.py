@@ -240,7 +240,7 @@ _OUT_OF_SCOPE_KWARGS = (
     "end_image", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
     "control_video", "reference_image", "camera_control_direction", "vace_video", "vace_video_mask",
     "vace_reference_image", "animate_pose_video", "animate_face_video", "animate_inpaint_video", "animate_mask_video",
-    "vap_video", "motion_bucket_id", "longcat_video", "sliding_window_size", "sliding_window_stride",
+    "vap_video", "motion_bucket_id", "longcat_video",
 )
 
 
@@ -407,7 +407,8 @@ class WanVideoPipeline(torch.nn.Module):
     def __call__(self, prompt, negative_prompt="", input_image=None, input_video=None, seed=None, rand_device="cpu", height=480, width=832,
                  num_frames=81, cfg_scale=5.0, cfg_merge=False, switch_DiT_boundary=0.875, num_inference_steps=50,
                  sigma_shift=5.0, denoising_strength=1.0, tiled=True, tile_size=(30, 52), tile_stride=(15, 26),
-                 tea_cache_l1_thresh=None, tea_cache_model_id="", progress_bar_cmd=tqdm, output_type="quantized",
+                 sliding_window_size=None, sliding_window_stride=None, tea_cache_l1_thresh=None, tea_cache_model_id="",
+                 progress_bar_cmd=tqdm, output_type="quantized",
                  first_frame_latents=None, **other):
         for name, value in other.items():
             if name not in _OUT_OF_SCOPE_KWARGS:
@@ -427,6 +428,7 @@ class WanVideoPipeline(torch.nn.Module):
             "seed": seed, "rand_device": rand_device, "height": height, "width": width, "num_frames": num_frames,
             "cfg_scale": cfg_scale, "cfg_merge": cfg_merge, "sigma_shift": sigma_shift,
             "tiled": tiled, "tile_size": tile_size, "tile_stride": tile_stride,
+            "sliding_window_size": sliding_window_size, "sliding_window_stride": sliding_window_stride,
         }
         for unit in self.units:
             inputs_shared, inputs_posi, inputs_nega = self.unit_runner(unit, self, inputs_shared, inputs_posi, inputs_nega)
@@ -459,7 +461,8 @@ class WanVideoPipeline(torch.nn.Module):
           ONE stream, each yielding right after it has started an exchange: branch B's GEMMs run while A's tensors cross
           xGMI, A's attention / FFN while B's do.  Collectives keep one program order on every rank."""
         models = {name: getattr(self, name) for name in self.in_iteration_models}
-        shared = {k: v for k, v in inputs_shared.items() if k in ("latents", "fuse_vae_embedding_in_latents")}
+        shared = {k: v for k, v in inputs_shared.items()
+                  if k in ("latents", "fuse_vae_embedding_in_latents", "sliding_window_size", "sliding_window_stride")}
         shared["sequence_shard"] = self.sequence_shard
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
@@ -526,8 +529,36 @@ def run_interleaved(generators):
     return results
 
 
+def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window_stride):
+    """TemporalTiler_BCTHW.run (pipelines/wan_video.py:1069-1118) as a generator: overlapping windows of latent frames,
+    each an independent forward (`window_fn(window)` is a step generator), blended with linear ramps of width
+    size - stride; accumulation in the data dtype on the device, in the reference's order."""
+    b, c, t_all, h, w = latents.shape
+    value = torch.zeros((b, c, t_all, h, w), dtype=latents.dtype, device=latents.device)
+    weight = torch.zeros((1, 1, t_all, 1, 1), dtype=latents.dtype, device=latents.device)
+    border = sliding_window_size - sliding_window_stride
+    for t in range(0, t_all, sliding_window_stride):
+        if t - sliding_window_stride >= 0 and t - sliding_window_stride + sliding_window_size >= t_all:
+            continue
+        t_ = min(t + sliding_window_size, t_all)
+        out = yield from window_fn(latents[:, :, t:t_].contiguous())
+        mask = torch.ones((t_ - t,))
+        if border > 0:
+            ramp = (torch.arange(border) + 0.5) / border
+            if t != 0:
+                mask[:border] = ramp
+            if t_ != t_all:
+                mask[-border:] = torch.flip(ramp, dims=(0,))
+        mask = mask.view(1, 1, -1, 1, 1).to(device=latents.device, dtype=latents.dtype)
+        value[:, :, t:t_] += out * mask
+        weight[:, :, t:t_] += mask
+    value /= weight
+    return value
+
+
 def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
-                             sequence_shard=None, gather_output=True, tea_cache=None, **kwargs):
+                             sequence_shard=None, gather_output=True, tea_cache=None, sliding_window_size=None,
+                             sliding_window_stride=None, **kwargs):
     """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction, or
     with gather_output=False the head output of this rank's tokens (1, n_local, out_dim*prod(patch)) and the grid).
 
@@ -536,6 +567,15 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     go through time_embedding / time_projection once and the kernels index them by token position.
     """
     assert latents.shape[0] == 1, "batch 1 (cfg_merge is not on the hot path)"
+    if sliding_window_size is not None and sliding_window_stride is not None:
+        # the reference's approximate long-video mode (:1158-1182).  Its window calls do not receive
+        # fuse_vae_embedding_in_latents (absent from its model_kwargs), so they run in the single-timestep mode.
+        if not gather_output:
+            raise NotImplementedError("sliding windows need whole predictions: use a cfg_parallel=1 layout")
+        return (yield from temporal_tiler_steps(
+            lambda win: model_fn_wan_video_steps(dit, latents=win, timestep=timestep, context=context,
+                                                 sequence_shard=sequence_shard, tea_cache=tea_cache),
+            latents, sliding_window_size, sliding_window_stride))
     dev, dt = latents.device, latents.dtype
     tval = timestep.detach().to("cpu")
     ti2v = dit.seperated_timestep and fuse_vae_embedding_in_latents

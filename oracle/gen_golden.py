@@ -107,6 +107,11 @@ def section_serving(R):
                 out[f"{mode}_acc{pid}"] = torch.tensor([float(tc.accumulated_rel_l1_distance) for tc in tea], dtype=torch.float64)
         out[f"{mode}_skipped"] = torch.tensor(skipped)
         print(mode, "skipped (posi, nega) per step:", skipped)
+    # sliding-window mode of model_fn_wan_video (TemporalTiler_BCTHW): 7 latent frames, windows of 4 with stride 2
+    lat7 = seeded((1, 48, 7, 8, 8), 98)
+    with torch.no_grad():
+        out["sliding_window_out"] = fn(dit=model, latents=lat7, timestep=torch.tensor([700.0]).to(torch.bfloat16), context=ctx_p,
+                                       fuse_vae_embedding_in_latents=True, sliding_window_size=4, sliding_window_stride=2)
     # hot-loaded LoRA: AutoWrappedLinear.forward = linear_forward, then lora_forward (core/vram/layers.py:410-436) with the
     # lists load_lora fills (alpha folded into A, base_pipeline.py:258); two stacked adapters
     from diffsynth.core.vram.layers import AutoWrappedLinear
@@ -124,10 +129,10 @@ def section_serving(R):
     save("serving.safetensors", out, {
         "config": str(kw), "weights": "synthetic.random_state_dict(dit_shapes(TINY_DIT_KWARGS), seed=1234)",
         "inputs": f"as dit_tiny.safetensors; {steps} steps cfg 5 shift 5; TeaCache(rel_l1_thresh={thresh}, model_id={model_id!r}) per CFG branch; "
-                  "t2v: fuse_vae_embedding_in_latents=False (no first-frame pin); hot LoRA: x=seeded((1,40,256),91) w=seed 92 x0.05 (384,256) "
+                  "t2v: fuse_vae_embedding_in_latents=False (no first-frame pin); sliding window: latents=seeded((1,48,7,8,8),98) t=bf16(700) ctx+ size 4 stride 2; hot LoRA: x=seeded((1,40,256),91) w=seed 92 x0.05 (384,256) "
                   "b=seed 93 x0.1; adapters (A1 seed 94 (4,256), B1 seed 95, alpha 0.5), (A2 seed 96 (8,256), B2 seed 97, alpha 2), all x0.05",
         "source": "diffsynth/pipelines/wan_video.py TeaCache :1016-1065, model_fn_wan_video :1297-1300,1316-1317,1375-1376; "
-                  "core/vram/layers.py AutoWrappedLinear.lora_forward :417-428; base_pipeline.py:249-262"})
+                  "core/vram/layers.py AutoWrappedLinear.lora_forward :417-428; base_pipeline.py:249-262; TemporalTiler_BCTHW :1069-1118"})
 
 
 def main():

@@ -254,3 +254,36 @@ def model_fn(sd, cfg, latents, timestep, context, fuse_vae_embedding_in_latents=
             tea_cache.store(x)
     x = head(sd, x, t, eps)
     return unpatchify(x, (f, h, w), patch, cfg["out_dim"])
+
+
+def temporal_tiler(model_fn_, latents, sliding_window_size, sliding_window_stride):
+    """TemporalTiler_BCTHW.run, pipelines/wan_video.py:1069-1118: overlapping windows of latent frames, each an independent
+    forward, blended with linear ramps of width (size - stride) in the data dtype.  `model_fn_(window) -> prediction`."""
+    b, c, t_all, h, w = latents.shape
+    value = torch.zeros((b, c, t_all, h, w), dtype=latents.dtype)
+    weight = torch.zeros((1, 1, t_all, 1, 1), dtype=latents.dtype)
+    border = sliding_window_size - sliding_window_stride
+    for t in range(0, t_all, sliding_window_stride):
+        if t - sliding_window_stride >= 0 and t - sliding_window_stride + sliding_window_size >= t_all:
+            continue
+        t_ = min(t + sliding_window_size, t_all)
+        out = model_fn_(latents[:, :, t:t_])
+        mask = torch.ones((t_ - t,))
+        if border > 0:
+            ramp = (torch.arange(border) + 0.5) / border
+            if t != 0:
+                mask[:border] = ramp
+            if t_ != t_all:
+                mask[-border:] = torch.flip(ramp, dims=(0,))
+        mask = mask.view(1, 1, -1, 1, 1).to(latents.dtype)
+        value[:, :, t:t_] += out * mask
+        weight[:, :, t:t_] += mask
+    value /= weight
+    return value
+
+
+def model_fn_sliding(sd, cfg, latents, timestep, context, sliding_window_size, sliding_window_stride, num_blocks=None):
+    """model_fn_wan_video with sliding_window_size / stride (:1158-1182).  The window calls do not receive
+    fuse_vae_embedding_in_latents (it is not in the reference's model_kwargs), so they run in the single-timestep mode."""
+    return temporal_tiler(lambda win: model_fn(sd, cfg, win, timestep, context, False, num_blocks),
+                          latents, sliding_window_size, sliding_window_stride)

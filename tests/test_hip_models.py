@@ -111,6 +111,22 @@ def test_teacache_loop_vs_golden(tiny_dit, golden):
         assert cos(out, g[f"{mode}_step7"]) > 0.999, mode
 
 
+def test_sliding_window_vs_golden(tiny_dit, golden):
+    """model_fn_wan_video(..., sliding_window_size=4, sliding_window_stride=2): the reference's TemporalTiler windows and
+    ramps (including its quirk that the window calls run in the single-timestep mode)."""
+    from fairygen_amd.wan_video import model_fn_wan_video
+    g = golden("serving.safetensors")
+    m, sd, cfg = tiny_dit
+    _, ctx_p, _, _, _ = _tiny_inputs()
+    lat7 = seeded((1, 48, 7, 8, 8), 98)
+    with torch.no_grad():
+        out = model_fn_wan_video(m, latents=lat7.cuda(), timestep=torch.tensor([700.0]).to(torch.bfloat16), context=ctx_p.cuda(),
+                                 fuse_vae_embedding_in_latents=True, sliding_window_size=4, sliding_window_stride=2)
+    want = g["sliding_window_out"]
+    assert out.shape == want.shape and cos(out, want) > 0.9995
+    assert (out.float().cpu() - want.float()).abs().max().item() < 0.08
+
+
 def test_lora_hotload_and_clear(golden):
     """pipe.load_lora(..., hotload=True) keeps the adapters unfused (AutoWrappedLinear.lora_forward arithmetic, pinned by the
     golden vector of one Linear), matches the fused model within bf16 noise, and pipe.clear_lora() restores the base

@@ -103,6 +103,15 @@ def test_fp8_linear_restatement():
     assert rel < 0.08                                         # e4m3 weights of magnitude 0.05: ~4 % mean error
 
 
+def test_sliding_window_model_fn(golden):
+    g = golden("serving.safetensors")
+    cfg = synthetic.TINY_DIT_KWARGS
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    _, ctx_p, _, _, _ = _tiny_inputs()
+    got = wan_dit.model_fn_sliding(sd, cfg, seeded((1, 48, 7, 8, 8), 98), torch.tensor([700.0]).to(torch.bfloat16), ctx_p, 4, 2)
+    assert torch.equal(got, g["sliding_window_out"])
+
+
 def test_scheduler(golden):
     g = golden("scheduler.safetensors")
     for n in (4, 30, 50):
