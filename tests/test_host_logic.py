@@ -205,3 +205,35 @@ def test_teacache_rows_form_matches_dense():
     assert decisions[0] == decisions[1] == [False, True, True, False, True, False]
     with pytest.raises(ValueError, match="not a supported TeaCache model id"):
         TeaCache(4, 0.1, "Wan2.2-TI2V-5B")
+
+
+def test_save_video_fallback_writes_a_playable_mjpeg_avi(tmp_path):
+    """Without imageio/ffmpeg (this image) save_video writes <path>.avi: a RIFF AVI whose header, index and JPEG frames
+    parse back (frame count, size, rate) and whose frames decode to the input within JPEG error."""
+    import io
+    import struct
+    import numpy as np
+    from PIL import Image
+    from fairygen_amd import save_video
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, size=(8, 12, 3), dtype=np.uint8).repeat(8, 0).repeat(8, 1)        # 64x96 blocks
+    frames = [Image.fromarray(np.roll(base, 8 * i, axis=1)) for i in range(5)]
+    out = save_video(frames, str(tmp_path / "clip.mp4"), fps=15, quality=9)
+    assert out.endswith("clip.mp4.avi")
+    data = open(out, "rb").read()
+    assert data[:4] == b"RIFF" and data[8:12] == b"AVI " and struct.unpack("<I", data[4:8])[0] == len(data) - 8
+    avih = data.index(b"avih")
+    usec, _, _, _, n, _, streams, _, w, h = struct.unpack("<10I", data[avih + 8: avih + 48])
+    assert (n, streams, w, h) == (5, 1, 96, 64) and abs(1e6 / usec - 15) < 0.01
+    movi = data.index(b"movi")
+    idx1 = data.index(b"idx1", movi)
+    entries = struct.unpack("<I", data[idx1 + 4: idx1 + 8])[0] // 16
+    assert entries == 5
+    for i in range(entries):
+        tag, _, off, size = struct.unpack("<4sIII", data[idx1 + 8 + 16 * i: idx1 + 24 + 16 * i])
+        start = movi + off                                              # offsets are relative to the 'movi' fourcc
+        assert tag == b"00dc" and data[start: start + 4] == b"00dc" and struct.unpack("<I", data[start + 4: start + 8])[0] == size
+        got = np.array(Image.open(io.BytesIO(data[start + 8: start + 8 + size])).convert("RGB")).astype(int)
+        assert np.abs(got - np.array(frames[i]).astype(int)).mean() < 12
+    with pytest.raises(ValueError):
+        save_video([], str(tmp_path / "empty.mp4"), fps=15)
