@@ -87,7 +87,8 @@ def _ulysses_worker(rank, world, port, n_tokens, heads, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_tokens,heads,port", [(2, 105, 4, 29634), (3, 10, 6, 29635), (4, 64, 4, 29636)])
+@pytest.mark.parametrize("world,n_tokens,heads,port", [(2, 105, 4, 29634), (3, 10, 6, 29635), (4, 64, 4, 29636),
+                                                       (8, 43, 24, 29644)])      # the 8-GPU case: 3 of 24 heads per rank
 def test_ulysses_exchange_gloo(tmp_path, world, n_tokens, heads, port):
     mp.spawn(_ulysses_worker, args=(world, port, n_tokens, heads, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
@@ -121,7 +122,7 @@ def _layout_worker(rank, world, port, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,port", [(2, 29637), (4, 29638)])
+@pytest.mark.parametrize("world,port", [(2, 29637), (4, 29638), (8, 29645)])
 def test_cfg_parallel_layout_gloo(tmp_path, world, port):
     mp.spawn(_layout_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
