@@ -126,7 +126,8 @@ def candidate_layouts(world, num_heads):
 
 
 def cpu_baseline(args, n_tokens, frames, steps):
-    """The CPU oracle ("port" of the reference's PyTorch path, pinned bit-exact to it by tests/golden) timed on the
+    """The CPU oracle ("port" of the reference's PyTorch path, pinned bit-exact to it by tests/golden — at full model width by
+    oracle/gen_config1.py, where the reference itself took 25.0 s/clip and this port 24.1 s on config 1) timed on the
     host cores on a bounded sample, extrapolated to the clip: one full-width DiT block at Ns tokens (GEMM part scaled
     by N/Ns, SDPA part by (N/Ns)^2, x30 blocks x2 CFG branches x steps) + VAE38 decode of a (1,48,2,4,4) latent scaled by
     pixel-frames."""

@@ -112,6 +112,31 @@ def test_sliding_window_model_fn(golden):
     assert torch.equal(got, g["sliding_window_out"])
 
 
+def test_oracle_full_width_config1(golden):
+    """The oracle at the FULL Wan2.2-TI2V-5B widths (30 blocks, dim 3072) on BASELINE.json configs[0]: the first two denoise
+    steps must equal, bit for bit, the latents the reference's own code produced (oracle/gen_config1.py; there all four
+    steps and the decoded video were bit-identical, reference 25.0 s vs restatement 24.1 s per clip on 8 cores)."""
+    from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
+    g = golden("config1.safetensors")
+    cfg = dict(TI2V_5B_DIT_KWARGS)
+    sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
+    noise = seeded((1, 48, 5, 16, 16), 1)
+    ctx_p = seeded((1, 512, 4096), 2); ctx_p[:, 64:] = 0
+    ctx_n = seeded((1, 512, 4096), 3); ctx_n[:, 128:] = 0
+    z0 = seeded((1, 48, 1, 16, 16), 4)
+    sig, ts = opipe.wan_sigmas(4, shift=5.0)
+    lat = noise.clone()
+    lat[:, :, 0:1] = z0
+    with torch.no_grad():
+        for i in range(2):
+            t = ts[i].unsqueeze(0).to(torch.bfloat16)
+            posi = wan_dit.model_fn(sd, cfg, lat, t, ctx_p, True)
+            nega = wan_dit.model_fn(sd, cfg, lat, t, ctx_n, True)
+            lat = opipe.euler_step(nega + 5.0 * (posi - nega), i, lat, sig)
+            lat[:, :, 0:1] = z0
+            assert torch.equal(lat, g[f"latents_step{i}"]), f"step {i}"
+
+
 def test_scheduler(golden):
     g = golden("scheduler.safetensors")
     for n in (4, 30, 50):
