@@ -434,6 +434,34 @@ def test_config1_full_width_vs_reference_golden(golden):
     torch.cuda.empty_cache()
 
 
+def test_config2_forward_full_width_vs_reference_golden(golden):
+    """One forward of BASELINE.json configs[1] (480x832x49: N = 5 070 tokens, a ragged 19.8 query blocks with the split-KV tail)
+    at the full model width against the reference's own bf16 prediction (oracle/gen_config2_forward.py; the oracle equalled
+    it bit for bit) with the fp32 evaluation as yardstick: max|hip - f32| <= 2 max|ref_bf16 - f32| + floor."""
+    from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
+    from fairygen_amd.wan_video import model_fn_wan_video
+    from fairygen_amd.wan_video_dit import WanModel
+    g = golden("config2_forward.safetensors")
+    cfg = dict(TI2V_5B_DIT_KWARGS)
+    with torch.device("meta"):
+        dit = WanModel(**cfg)
+    dit.load_state_dict(synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234), assign=True)
+    dit = dit.to(device="cuda", dtype=torch.bfloat16).eval()
+    lat = seeded((1, 48, 13, 30, 52), 1)
+    lat[:, :, 0:1] = seeded((1, 48, 1, 30, 52), 4)
+    ctx = seeded((1, 512, 4096), 2); ctx[:, 64:] = 0
+    with torch.no_grad():
+        out = model_fn_wan_video(dit, latents=lat.cuda(), timestep=torch.tensor([700.0]).to(torch.bfloat16), context=ctx.cuda(),
+                                 fuse_vae_embedding_in_latents=True)
+    sub, ref, f32 = out[:, ::6].float().cpu(), g["pred_bf16_ch6"].float(), g["pred_f32_ch6"]
+    assert sub.shape == ref.shape == f32.shape == (1, 8, 13, 30, 52)
+    err_ref, err = (ref - f32).abs().max().item(), (sub - f32).abs().max().item()
+    assert err <= 2 * err_ref + 1e-2, (err, err_ref)
+    assert cos(sub, ref) > 0.9995 and (sub - f32).abs().mean().item() <= 1.25 * (ref - f32).abs().mean().item() + 1e-4
+    del dit
+    torch.cuda.empty_cache()
+
+
 def _tiny_text_encoder():
     from fairygen_amd.wan_video_text_encoder import WanTextEncoder
     tkw = synthetic.TINY_TEXT_KWARGS
