@@ -484,6 +484,33 @@ def test_text_encoder_vs_golden(golden):
     assert cos(out, g["encoder_bf16"]) > 0.9995
 
 
+def test_text_encoder_full_width_vs_reference_golden(golden):
+    """umT5-XXL at its real size (24 layers, dim 4096, 64 heads, ffn 10240) on a 512-token prompt with 77 real tokens, against
+    the reference's own WanTextEncoder run on the CPU (oracle/gen_text_full.py; the oracle equalled it bit for bit)."""
+    from fairygen_amd.wan_video_text_encoder import WanTextEncoder
+    g = golden("text_full.safetensors")
+    sd = {k: (v * (50.0 if k.startswith("token_embedding") else 0.5) if v.dim() == 2 else v)        # as gen_text_full.py
+          for k, v in synthetic.random_state_dict(synthetic.text_encoder_shapes(), seed=1234).items()}
+    with torch.device("meta"):
+        enc = WanTextEncoder()
+    enc.load_state_dict(sd, assign=True)
+    enc = enc.to(device="cuda", dtype=torch.bfloat16).eval()
+    gen = torch.Generator("cpu").manual_seed(61)
+    ids = torch.randint(0, 256384, (1, 512), generator=gen)
+    mask = torch.zeros((1, 512), dtype=torch.long)
+    mask[:, :77] = 1
+    ids = ids * mask
+    with torch.no_grad():
+        emb = enc(ids.cuda(), mask.cuda())
+        emb[:, 77:] = 0
+    sub, ref, f32 = emb[..., ::16].float().cpu(), g["emb_bf16_ch16"].float(), g["emb_f32_ch16"]
+    err_ref, err = (ref - f32).abs().max().item(), (sub - f32).abs().max().item()
+    assert sub.shape == ref.shape == (1, 512, 256) and err <= 2 * err_ref + 1e-2, (err, err_ref)
+    assert cos(sub, ref) > 0.998 and cos(sub, f32) >= cos(ref, f32) - 1e-3 and (sub[:, 77:] == 0).all()
+    del enc
+    torch.cuda.empty_cache()
+
+
 def test_prompt_strings_through_tokenizer_and_text_encoder(tiny_dit, tiny_vae):
     """prompt=str path: pipe.tokenizer(prompt, return_mask=True) -> umT5 -> rows >= seq_len zeroed (reference
     pipelines/wan_video.py:404-412), with a stand-in tokenizer object of the HuggingfaceTokenizer call shape."""
