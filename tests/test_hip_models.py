@@ -299,6 +299,28 @@ def test_tiny_vae_encode_vs_golden(tiny_vae, golden):
     assert torch.equal(zv[:, :, :1], z1), "the first latent frame depends on the first video frame only (causal encoder)"
 
 
+def test_fullwidth_vae_encoder_vs_reference_golden(golden):
+    """The VAE38 encoder at its real widths against the reference's own WanVideoVAE38.encode (oracle/gen_vae_encode_full.py):
+    a 256x256 first-frame image and a 9-frame clip (temporal stride-2 convolutions + caches)."""
+    from fairygen_amd.wan_video_vae import WanVideoVAE38
+    g = golden("vae_encode_full.safetensors")
+    with torch.device("meta"):
+        vae = WanVideoVAE38()
+    vae.load_state_dict(synthetic.random_state_dict(synthetic.vae_shapes(), seed=1234), assign=True)
+    vae = vae.to(device="cuda", dtype=torch.bfloat16).eval()
+    img = seeded((3, 1, 256, 256), 32, scale=0.5).clamp(-1, 1)
+    vid = seeded((3, 9, 128, 192), 33, scale=0.5).clamp(-1, 1)
+    with torch.no_grad():
+        for name, x in (("image", img), ("video", vid)):
+            z = vae.encode([x.cuda()], device="cuda").float().cpu()
+            ref, f32 = g[f"encode_{name}_bf16"].float(), g[f"encode_{name}_f32"]
+            err_ref, err = (ref - f32).abs().max().item(), (z - f32).abs().max().item()
+            assert z.shape == ref.shape and err <= 2 * err_ref + 2e-2, (name, err, err_ref)
+            assert cos(z, ref) > 0.9995, (name, cos(z, ref))
+    del vae
+    torch.cuda.empty_cache()
+
+
 def test_fullwidth_vae_decoder_small_latent_vs_oracle():
     """The real decoder widths (dec_dim 256: 1024/1024/1024/512/256 channels, 34 causal convs) on a small latent."""
     from fairygen_amd.wan_video_vae import WanVideoVAE38
