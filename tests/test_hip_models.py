@@ -321,6 +321,28 @@ def test_fullwidth_vae_encoder_vs_reference_golden(golden):
     torch.cuda.empty_cache()
 
 
+def test_fullwidth_tiled_vae_decode_vs_reference_golden(golden):
+    """inference.py's tiled decode ((30,52)/(15,26)) at full decoder width on a latent with a 2 x 2 tile grid and feathered
+    overlaps, against the reference's own WanVideoVAE38.decode(tiled=True) (oracle/gen_vae_tiled_full.py: 115 s on 8 cores)."""
+    from fairygen_amd.wan_video_vae import WanVideoVAE38
+    g = golden("vae_tiled_full.safetensors")
+    with torch.device("meta"):
+        vae = WanVideoVAE38()
+    vae.load_state_dict(synthetic.random_state_dict(synthetic.vae_shapes(), seed=1234), assign=True)
+    vae = vae.to(device="cuda", dtype=torch.bfloat16).eval()
+    z = seeded((1, 48, 2, 40, 60), 35)
+    with torch.no_grad():
+        video = vae.decode(z.cuda(), device="cuda", tiled=True, tile_size=(30, 52), tile_stride=(15, 26))
+    assert tuple(video.shape) == (1, 3, 5, 640, 960)
+    sub, ref, f32 = video[..., 3::8, 3::8].float().cpu(), g["video_bf16_sub8"].float(), g["video_f32_sub8"]
+    err_ref, err = (ref - f32).abs().max().item(), (sub - f32).abs().max().item()
+    assert err <= 2 * err_ref + 2e-2, (err, err_ref)
+    assert cos(sub, ref) > 0.9995
+    assert (sub - f32).abs().mean().item() <= 1.25 * (ref - f32).abs().mean().item() + 1e-3
+    del vae
+    torch.cuda.empty_cache()
+
+
 def test_fullwidth_vae_decoder_small_latent_vs_oracle():
     """The real decoder widths (dec_dim 256: 1024/1024/1024/512/256 channels, 34 causal convs) on a small latent."""
     from fairygen_amd.wan_video_vae import WanVideoVAE38
