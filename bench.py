@@ -106,7 +106,7 @@ class KernelTimer:
                 "traffic": PMC_HBM_BYTES_PER_LAUNCH.get(shape)}
 
 
-LAYOUTS = ("cfg1-allgather", "cfg1-ulysses", "cfg2-allgather", "cfg2-ulysses")
+LAYOUTS = ("cfg1-allgather", "cfg1-ulysses", "cfg2-allgather", "cfg2-ulysses", "cfg1-windows")
 
 
 def candidate_layouts(world, num_heads):
@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--gelu-epilogue", type=int, default=1, help="0: separate GELU kernel after ffn.0 instead of the GEMM epilogue")
     ap.add_argument("--linear-dtype", default="bf16", choices=("bf16", "fp8"),
                     help="fp8: the reference's fp8 Linear mode for the DiT blocks (config 5's weight path); NOT the headline config")
+    ap.add_argument("--sliding-window", default="", metavar="SIZE,STRIDE",
+                    help="the reference's APPROXIMATE sliding-window mode (latent frames per window, stride); with --layout "
+                         "cfg1-windows the windows are dealt to the ranks.  Never the headline configuration")
     ap.add_argument("--layout", default=os.environ.get("FAIRYGEN_PARALLEL", "auto"), choices=("auto",) + LAYOUTS,
                     help="N>1: how the ranks are used (auto: time every candidate for one step in the warm-up, keep the fastest)")
     args = ap.parse_args()
@@ -205,6 +208,8 @@ def main():
     pipe.dit.gelu_epilogue = bool(args.gelu_epilogue)
     if args.linear_dtype == "fp8":
         pipe.dit.enable_fp8_linear(torch.float8_e4m3fn)
+    if args.layout == "cfg1-windows" and not args.sliding_window:
+        ap.error("--layout cfg1-windows needs --sliding-window SIZE,STRIDE")
     if world > 1 and args.layout != "auto":
         cfgp, mode = args.layout.split("-")
         pipe.enable_sequence_parallel(cfg_parallel=int(cfgp[3:]), attn_mode=mode)
@@ -222,6 +227,9 @@ def main():
         latents = noise.clone()
         latents[:, :, 0:1] = z0
         shared = {"latents": latents, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0}
+        if args.sliding_window:
+            size, stride = (int(v) for v in args.sliding_window.split(","))
+            shared.update(sliding_window_size=size, sliding_window_stride=stride)
         latents = pipe.denoise(shared, {"context": ctx_p}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x)
         if not decode:
             return latents, None
@@ -305,6 +313,8 @@ def main():
             "roofline": roofline,
         }
         line["config"]["gelu"] = "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel"
+        if args.sliding_window:
+            line["config"]["APPROXIMATE_sliding_window"] = args.sliding_window + " (reference TemporalTiler mode, not the default path)"
         if autotune is not None:
             line["config"]["layout_autotune_ms_per_step"] = autotune
         if args.layers:

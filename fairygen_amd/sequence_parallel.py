@@ -13,6 +13,12 @@ the exact "halo" of a temporal shard is the whole sequence; two
   all-to-all brings the output back (2 collectives, 4·(N/P)·3072·2 B·(P-1)/P sent per rank: 73 MB at P = 8 —
   a quarter of the all-gather traffic, and on the fully connected xGMI mesh every peer pair uses its own link).
 
+* ``attn_mode="windows"`` — NOT exact: the reference's sliding-window mode (``TemporalTiler_BCTHW``,
+  ``pipelines/wan_video.py:1069-1118``; ``sliding_window_size=`` / ``sliding_window_stride=`` on the call) with its overlapping
+  windows of latent frames dealt to the ranks: latent-temporal shards whose overlap frames are the halo, no exchange inside
+  a forward, one all-gather of the window outputs per forward, the reference's ramp blend on every rank.  Results equal the
+  single-GPU sliding-window call bit for bit, and differ from the default (full 3-D attention) call like the reference's do.
+
 On top of either, the two CFG branches of a denoise step are independent until the combine
 (``pipelines/wan_video.py:296-301``), so ``ParallelLayout(cfg_parallel=2)`` gives each half of the ranks one
 branch (sequence-parallel inside the half) and exchanges the two predictions with ONE world all-gather per step.
@@ -23,7 +29,7 @@ the several-ranks-on-one-GPU rehearsal, where device tensors are staged through 
 import torch
 import torch.distributed as dist
 
-ATTN_MODES = ("allgather", "ulysses")
+ATTN_MODES = ("allgather", "ulysses", "windows")
 
 
 def _staged(t, group):

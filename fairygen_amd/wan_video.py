@@ -529,19 +529,46 @@ def run_interleaved(generators):
     return results
 
 
-def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window_stride):
+def temporal_windows(t_all, sliding_window_size, sliding_window_stride):
+    """The (t, t_) latent-frame ranges TemporalTiler_BCTHW.run visits (pipelines/wan_video.py:1097-1100)."""
+    out = []
+    for t in range(0, t_all, sliding_window_stride):
+        if t - sliding_window_stride >= 0 and t - sliding_window_stride + sliding_window_size >= t_all:
+            continue
+        out.append((t, min(t + sliding_window_size, t_all)))
+    return out
+
+
+def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window_stride, window_shard=None):
     """TemporalTiler_BCTHW.run (pipelines/wan_video.py:1069-1118) as a generator: overlapping windows of latent frames,
     each an independent forward (`window_fn(window)` is a step generator), blended with linear ramps of width
-    size - stride; accumulation in the data dtype on the device, in the reference's order."""
+    size - stride; accumulation in the data dtype on the device, in the reference's order.
+
+    window_shard (a multi-rank sequence_parallel.TokenShard with attn_mode "windows"): the windows are dealt round-robin to
+    the ranks — latent-temporal shards whose overlap frames are the halo — each rank runs its windows' forwards with no exchange
+    inside them, one all-gather per call collects the window outputs, and every rank blends all of them in the reference's
+    order: bit-identical to the single-GPU sliding-window result."""
     b, c, t_all, h, w = latents.shape
     value = torch.zeros((b, c, t_all, h, w), dtype=latents.dtype, device=latents.device)
     weight = torch.zeros((1, 1, t_all, 1, 1), dtype=latents.dtype, device=latents.device)
     border = sliding_window_size - sliding_window_stride
-    for t in range(0, t_all, sliding_window_stride):
-        if t - sliding_window_stride >= 0 and t - sliding_window_stride + sliding_window_size >= t_all:
-            continue
-        t_ = min(t + sliding_window_size, t_all)
-        out = yield from window_fn(latents[:, :, t:t_].contiguous())
+    windows = temporal_windows(t_all, sliding_window_size, sliding_window_stride)
+    world, rank = (window_shard.world_size, window_shard.rank) if window_shard is not None else (1, 0)
+    outs = {}
+    for i, (t, t_) in enumerate(windows):
+        if i % world == rank:
+            outs[i] = yield from window_fn(latents[:, :, t:t_].contiguous())
+    if world > 1:
+        # one collective: every rank contributes its windows, zero-padded to `sliding_window_size` frames, in slot order
+        per_rank = (len(windows) + world - 1) // world
+        slot = c * sliding_window_size * h * w
+        send = torch.zeros((per_rank, slot), dtype=latents.dtype, device=latents.device)
+        for i, o in outs.items():
+            send[i // world, : o.numel()] = o.reshape(-1)
+        full = window_shard._gather_rows(send, per_rank).view(world, per_rank, slot)
+        for i, (t, t_) in enumerate(windows):
+            outs[i] = full[i % world, i // world, : c * (t_ - t) * h * w].view(b, c, t_ - t, h, w)
+    for i, (t, t_) in enumerate(windows):
         mask = torch.ones((t_ - t,))
         if border > 0:
             ramp = (torch.arange(border) + 0.5) / border
@@ -550,7 +577,7 @@ def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window
             if t_ != t_all:
                 mask[-border:] = torch.flip(ramp, dims=(0,))
         mask = mask.view(1, 1, -1, 1, 1).to(device=latents.device, dtype=latents.dtype)
-        value[:, :, t:t_] += out * mask
+        value[:, :, t:t_] += outs[i] * mask
         weight[:, :, t:t_] += mask
     value /= weight
     return value
@@ -572,10 +599,17 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         # fuse_vae_embedding_in_latents (absent from its model_kwargs), so they run in the single-timestep mode.
         if not gather_output:
             raise NotImplementedError("sliding windows need whole predictions: use a cfg_parallel=1 layout")
+        by_window = sequence_shard is not None and sequence_shard.world_size > 1 and sequence_shard.attn_mode == "windows"
+        if by_window and tea_cache is not None:
+            raise NotImplementedError("TeaCache carries state from window to window (the reference shares one object across "
+                                      "them); windows dealt to different ranks cannot reproduce that order")
         return (yield from temporal_tiler_steps(
             lambda win: model_fn_wan_video_steps(dit, latents=win, timestep=timestep, context=context,
-                                                 sequence_shard=sequence_shard, tea_cache=tea_cache),
-            latents, sliding_window_size, sliding_window_stride))
+                                                 sequence_shard=None if by_window else sequence_shard, tea_cache=tea_cache),
+            latents, sliding_window_size, sliding_window_stride, sequence_shard if by_window else None))
+    if sequence_shard is not None and sequence_shard.world_size > 1 and sequence_shard.attn_mode == "windows":
+        raise ValueError('attn_mode="windows" shards the sliding-window mode: pass sliding_window_size= and '
+                         'sliding_window_stride= (the exact path shards with "ulysses" or "allgather")')
     dev, dt = latents.device, latents.dtype
     tval = timestep.detach().to("cpu")
     ti2v = dit.seperated_timestep and fuse_vae_embedding_in_latents

@@ -174,6 +174,43 @@ def test_list_shots_and_single_process_scheduler(tmp_path):
         replica_ranks(8, 3)
 
 
+def _windows_worker(rank, world, port, result_dir):
+    """attn_mode="windows": the sliding-window mode's windows dealt to ranks + one all-gather + the reference's blend must equal
+    the sequential TemporalTiler result bit for bit (CPU tensors, a stand-in window function)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd.sequence_parallel import TokenShard
+        from fairygen_amd.wan_video import temporal_tiler_steps, temporal_windows
+        lat = seeded((1, 6, 11, 4, 5), 70)
+
+        def window_fn(win):                      # a generator like model_fn_wan_video_steps, without exchanges
+            return (win.float() * 1.5 + win.float().mean(dim=2, keepdim=True)).to(win.dtype)
+            yield
+
+        def run(shard):
+            gen = temporal_tiler_steps(window_fn, lat, 4, 3, shard)
+            while True:
+                try:
+                    next(gen)
+                except StopIteration as done:
+                    return done.value
+        assert temporal_windows(11, 4, 3) == [(0, 4), (3, 7), (6, 10), (9, 11)]
+        want = run(None)
+        got = run(TokenShard(attn_mode="windows"))
+        assert torch.equal(got, want)
+        assert temporal_windows(7, 4, 2) == [(0, 4), (2, 6), (4, 7)] and temporal_windows(5, 8, 4) == [(0, 5)]
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29646), (3, 29647), (5, 29648)])
+def test_window_parallel_tiler_gloo(tmp_path, world, port):
+    mp.spawn(_windows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
 def test_assign_tiles_balances_by_area():
     from fairygen_amd.sequence_parallel import assign_tiles
     from fairygen_amd.wan_video_vae import WanVideoVAE38
@@ -285,6 +322,48 @@ def _gpu_replica_worker(rank, world, port, result_dir):
         open(os.path.join(result_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_windows_worker(rank, world, port, result_dir):
+    """attn_mode="windows" on the device: the sliding-window denoise loop with its windows dealt over gloo ranks sharing the
+    test GPU equals the single-process sliding-window loop bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairygen_amd import synthetic
+        from fairygen_amd.wan_video import WanVideoPipeline
+        from fairygen_amd.wan_video_dit import WanModel
+        cfg = dict(synthetic.TINY_DIT_KWARGS, dim=512, num_heads=4, ffn_dim=1024)
+        m = WanModel(**cfg)
+        m.load_state_dict(synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=77))
+        m = m.to(device="cuda", dtype=torch.bfloat16).eval()
+        lat = seeded((1, 48, 9, 10, 14), 5).cuda()
+        ctx, ctx_n = seeded((1, 24, 128), 6).cuda(), seeded((1, 24, 128), 7).cuda()
+        outs = []
+        for sharded in (False, True):
+            pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+            pipe.dit = m
+            if sharded:
+                pipe.enable_sequence_parallel(attn_mode="windows")
+            pipe.scheduler.set_timesteps(2, denoising_strength=1.0, shift=5.0)
+            shared = {"latents": lat.clone(), "fuse_vae_embedding_in_latents": False, "first_frame_latents": None,
+                      "sliding_window_size": 4, "sliding_window_stride": 2}
+            with torch.no_grad():
+                outs.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])
+        with pytest.raises(ValueError, match="sliding_window_size"):
+            pipe.denoise({"latents": lat.clone(), "fuse_vae_embedding_in_latents": False}, {"context": ctx}, {"context": ctx_n}, 5.0,
+                         progress_bar_cmd=lambda x: x)
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_window_parallel_on_gpu(tmp_path):
+    mp.spawn(_gpu_windows_worker, args=(3, 29649, str(tmp_path)), nprocs=3, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(3))
 
 
 @pytest.mark.gpu
