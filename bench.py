@@ -28,10 +28,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
-# HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r01_attn_pmc_hbm.json:
+# HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r01d_attn_pmc_hbm.json:
 # separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, gfx950 x2 correction on FETCH_SIZE), keyed by (Nq, Nkv, H).
 # PMC collection cannot run inside the timed bench; other shapes report null.
-PMC_HBM_BYTES_PER_LAUNCH = {(27280, 27280, 24): 2.094e9}
+PMC_HBM_BYTES_PER_LAUNCH = {(27280, 27280, 24): 2.089e9}
 
 
 def seeded(shape, seed, dtype=torch.bfloat16):
