@@ -579,3 +579,41 @@ def test_prompt_strings_through_tokenizer_and_text_encoder(tiny_dit, tiny_vae):
     want = wan_text.encode_prompt(sd, ids, mask, tkw["num_heads"])
     assert ctx.shape == want.shape == (1, 24, tkw["dim"])
     assert not ctx[:, 7:].any() and cos(ctx, want) > 0.9995
+
+
+def test_batch_inference_folder_loop(tmp_path, tiny_dit, tiny_vae):
+    """batch_inference.py end to end on one GPU: every <name>.png + <name>.txt of a folder -> pipe(prompt=str, input_image=PIL)
+    -> save_video; an image without a prompt file is skipped like in the reference."""
+    import numpy as np
+    from PIL import Image
+    from fairygen_amd.batch import ShotScheduler
+    from fairygen_amd.wan_video import WanVideoPipeline
+    enc, _, _ = _tiny_text_encoder()
+    m, _, _ = tiny_dit
+    vae, _ = tiny_vae
+
+    class FakeTokenizer:
+        def __call__(self, text, return_mask=False, add_special_tokens=True):
+            words = text.split()[:20]
+            ids, mask = torch.zeros((1, 24), dtype=torch.long), torch.zeros((1, 24), dtype=torch.long)
+            ids[0, : len(words) + 1] = torch.tensor([(sum(map(ord, w)) % 97) + 1 for w in words] + [1])
+            mask[0, : len(words) + 1] = 1
+            return (ids, mask) if return_mask else ids
+
+    pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+    pipe.dit, pipe.vae, pipe.text_encoder, pipe.tokenizer = m, vae, enc, FakeTokenizer()
+    pipe.height_division_factor = pipe.width_division_factor = 32
+    src, dst = tmp_path / "shots", tmp_path / "out"
+    src.mkdir()
+    rng = np.random.default_rng(1)
+    for name in ("1", "2", "3"):
+        Image.fromarray(rng.integers(0, 256, size=(70, 90, 3), dtype=np.uint8)).save(src / f"{name}.png")
+    (src / "1.txt").write_text("a pig walks towards the camera")
+    (src / "3.txt").write_text("the pig turns around")
+    done = ShotScheduler(replica_size=2).run_folder(pipe, str(src), str(dst), negative_prompt="blurry", size=(64, 64), fps=15,
+                                                    quality=5, num_frames=9, num_inference_steps=2, seed=1, height=64, width=64,
+                                                    tiled=False, progress_bar_cmd=lambda x: x)
+    assert [n for n, _ in done] == ["1", "3"]
+    for _, path in done:
+        data = open(path, "rb").read()
+        assert path.endswith(".mp4.avi") and data[:4] == b"RIFF" and data[8:12] == b"AVI "
