@@ -238,6 +238,12 @@ def main():
         video = pipe.decode_latents(latents, tiled=not args.untiled)
         return latents, video
 
+    def barrier():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
+
     def sync_max(t):
         if world == 1:
             return t
@@ -256,7 +262,7 @@ def main():
                 pipe.enable_sequence_parallel(cfg_parallel=cfgp, attn_mode=mode)
                 run_clip(1, decode=False)
                 torch.cuda.synchronize()
-                dist.barrier()
+                barrier()
                 t0 = time.perf_counter()
                 run_clip(2, decode=False)
                 torch.cuda.synchronize()
@@ -275,14 +281,14 @@ def main():
         timer = KernelTimer()
         timer.install()
         if world > 1:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize()
         t0 = phase["t0"] = time.perf_counter()
         latents, video = run_clip(args.steps, decode=not args.skip_vae)
         torch.cuda.synchronize()
         t_denoise_and_decode = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize()
         t_clip = time.perf_counter() - t0
         timer.uninstall()
