@@ -8,10 +8,12 @@ i mod (world / replica_size); a 2-GPU replica runs one CFG branch per GPU.  Sing
 """
 import argparse
 import os
+import sys
 
 import torch
 import torch.distributed as dist
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # the repo root: run from anywhere, no install
 from examples.inference import NEGATIVE, build_pipeline
 from fairygen_amd.batch import ShotScheduler
 

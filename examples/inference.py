@@ -6,11 +6,13 @@
 import argparse
 import glob
 import os
+import sys
 from pathlib import Path
 
 import torch
 from PIL import Image
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # the repo root: run from anywhere, no install
 from fairygen_amd import ModelConfig, WanVideoPipeline, save_video
 
 NEGATIVE = ("色调艳丽，过曝，静态，细节模糊不清，字幕，风格，作品，画作，画面，静止，整体发灰，最差质量，低质量，JPEG压缩残留，丑陋的，残缺的，多余的手指，"

@@ -157,10 +157,15 @@ __global__ __launch_bounds__(256) void residual_kernel(const bf16* __restrict__ 
     if (MODE == 1) norm_store<1>(r, C, lane, eps, p0, p1, norm_out + row * C);
 }
 
-// RMSNorm over the whole row, * weight, then RoPE on adjacent pairs in fp64 (as the reference does).
+// RMSNorm over the whole row, * weight, then RoPE on adjacent pairs.  F32TAB false: fp64 cos / sin tables and an fp64
+// rotation, the reference's arithmetic (43 us of fp64 VALU + 16-byte table loads per pair on top of the 77 us the
+// HBM-bound norm takes at N = 27 280).  F32TAB true: `ct` is ONE interleaved fp32 table (rows, head_dim/2, {cos, sin}) =
+// the fp64 table rounded once, rotation as two fp32 FMAs: the bf16 result differs from the fp64 one only where the
+// exact value lies within ~2e-7 relative of a bf16 rounding boundary (measured in tests/test_hip_kernels.py).
+template <bool F32TAB>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
-                                                           const bf16* __restrict__ w, const double* __restrict__ ct,
-                                                           const double* __restrict__ st, bf16* __restrict__ out,
+                                                           const bf16* __restrict__ w, const void* __restrict__ ctv,
+                                                           const void* __restrict__ stv, bf16* __restrict__ out,
                                                            int64_t rows, int C, int head_dim, float eps, int group_cols,
                                                            int64_t out_group_stride, int64_t out_ld) {
     const int lane = threadIdx.x & 63;
@@ -185,16 +190,28 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restric
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(r.v[i][j] * rinv) * (float)wv[j]);
-            if (ct != nullptr) {
+            if (ctv != nullptr) {
                 const int d0 = (vi * 8) % head_dim;          // channel within the head, multiple of 8
-                const double* cp = ct + row * half + (d0 >> 1);
-                const double* sp = st + row * half + (d0 >> 1);
+                if (F32TAB) {
+                    const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (d0 >> 1)) * 2);
+                    const f32x4 t0 = tp[0], t1 = tp[1];      // (c0,s0,c1,s1) (c2,s2,c3,s3)
+                    const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double a = (double)o[2 * j], b = (double)o[2 * j + 1];
-                    const double c = cp[j], s = sp[j];
-                    o[2 * j] = (float)(bf16)(a * c - b * s);
-                    o[2 * j + 1] = (float)(bf16)(a * s + b * c);
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = o[2 * j], b = o[2 * j + 1], c = cs[2 * j], sn = cs[2 * j + 1];
+                        o[2 * j] = rbf(__builtin_fmaf(a, c, -(b * sn)));
+                        o[2 * j + 1] = rbf(__builtin_fmaf(a, sn, b * c));
+                    }
+                } else {
+                    const double* cp = static_cast<const double*>(ctv) + row * half + (d0 >> 1);
+                    const double* sp = static_cast<const double*>(stv) + row * half + (d0 >> 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double a = (double)o[2 * j], b = (double)o[2 * j + 1];
+                        const double c = cp[j], sn = sp[j];
+                        o[2 * j] = (float)(bf16)(a * c - b * sn);
+                        o[2 * j + 1] = (float)(bf16)(a * sn + b * c);
+                    }
                 }
             }
             // column block g = col / group_cols goes to its own (rows, out_ld) plane (group_cols == C: plain rows)
@@ -321,29 +338,36 @@ int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_
     return fg_launch_status("fg_residual_ln_bf16");
 }
 
-int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight, const double* cos_tab, const double* sin_tab,
-                         void* out, int64_t rows, int C, int num_heads, float eps, fg_stream_t stream) {
+int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight, const void* cos_tab, const void* sin_tab,
+                         int table_f32, void* out, int64_t rows, int C, int num_heads, float eps, fg_stream_t stream) {
     if (int e = check_rows("fg_rmsnorm_rope_bf16", rows, C, 1, 0)) return e;
     FG_CHECK_ARG(x && weight && out, "fg_rmsnorm_rope_bf16: null pointer");
-    FG_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "fg_rmsnorm_rope_bf16: pass both tables or neither");
+    FG_CHECK_ARG(table_f32 ? (cos_tab != nullptr && sin_tab == nullptr) : ((cos_tab == nullptr) == (sin_tab == nullptr)),
+                 "fg_rmsnorm_rope_bf16: fp64 mode takes both tables or neither, fp32 mode ONE interleaved table in cos_tab");
     FG_CHECK_ARG(num_heads > 0 && C % num_heads == 0 && (C / num_heads) % 8 == 0,
                  "fg_rmsnorm_rope_bf16: head_dim must be a multiple of 8");
     FG_CHECK_ARG(ldx >= C && ldx % 8 == 0 && FG_ALIGNED16(x) && FG_ALIGNED16(weight) && FG_ALIGNED16(out) &&
                      FG_ALIGNED16(cos_tab) && FG_ALIGNED16(sin_tab),
                  "fg_rmsnorm_rope_bf16: pointers / ldx must be 16-byte aligned");
     if (rows == 0) return FG_OK;
-    hipLaunchKernelGGL(rmsnorm_rope_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
-                       (int64_t)C);
+    if (table_f32)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
+                           (int64_t)C);
+    else
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<false>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
+                           (int64_t)C);
     return fg_launch_status("fg_rmsnorm_rope_bf16");
 }
 
-int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight, const double* cos_tab,
-                                 const double* sin_tab, void* out, int64_t rows, int C, int num_heads, float eps,
+int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight, const void* cos_tab,
+                                 const void* sin_tab, int table_f32, void* out, int64_t rows, int C, int num_heads, float eps,
                                  int group_cols, int64_t out_group_stride, int64_t out_ld, fg_stream_t stream) {
     if (int e = check_rows("fg_rmsnorm_rope_grouped_bf16", rows, C, 1, 0)) return e;
     FG_CHECK_ARG(x && weight && out, "fg_rmsnorm_rope_grouped_bf16: null pointer");
-    FG_CHECK_ARG((cos_tab == nullptr) == (sin_tab == nullptr), "fg_rmsnorm_rope_grouped_bf16: pass both tables or neither");
+    FG_CHECK_ARG(table_f32 ? (cos_tab != nullptr && sin_tab == nullptr) : ((cos_tab == nullptr) == (sin_tab == nullptr)),
+                 "fg_rmsnorm_rope_grouped_bf16: fp64 mode takes both tables or neither, fp32 mode ONE interleaved table in cos_tab");
     FG_CHECK_ARG(num_heads > 0 && C % num_heads == 0 && (C / num_heads) % 8 == 0,
                  "fg_rmsnorm_rope_grouped_bf16: head_dim must be a multiple of 8");
     FG_CHECK_ARG(group_cols > 0 && group_cols % 8 == 0 && C % group_cols == 0 && out_ld >= group_cols && out_ld % 8 == 0 &&
@@ -353,9 +377,14 @@ int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight,
                      FG_ALIGNED16(cos_tab) && FG_ALIGNED16(sin_tab),
                  "fg_rmsnorm_rope_grouped_bf16: pointers / ldx must be 16-byte aligned");
     if (rows == 0) return FG_OK;
-    hipLaunchKernelGGL(rmsnorm_rope_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
-                       out_group_stride, out_ld);
+    if (table_f32)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
+                           out_group_stride, out_ld);
+    else
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<false>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
+                           out_group_stride, out_ld);
     return fg_launch_status("fg_rmsnorm_rope_grouped_bf16");
 }
 

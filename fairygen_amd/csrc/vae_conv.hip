@@ -431,6 +431,16 @@ int fg_conv_pack_weight_bf16(const void* w, void* packed, int Cout, int Cin, int
     return fg_launch_status("fg_conv_pack_weight_bf16");
 }
 
+int fg_conv_tile_choice(int T, int H, int W, int Cout) {
+    // the 256x256 LDS-DMA kernel when it fills the chip (>= one workgroup per CU) and Cout is a multiple of 256; the
+    // 128x128 kernel (two workgroups per CU) for the low-resolution layers and odd channel counts.
+    if (T <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % kT2 != 0) return 128;
+    const int64_t M = (int64_t)T * H * W;
+    const int64_t blocks256 = ((M + kT2 - 1) / kT2) * (roundup(Cout, kBMc) / kT2);
+    const int variant = conv_variant_override() ? conv_variant_override() : (blocks256 >= 224 ? 256 : 128);
+    return variant == 256 ? 256 : 128;
+}
+
 int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, const void* residual, void* out, int T, int H,
                       int W, int Cin, int Cout, int kt, int ks, int resample, int time_interleave, fg_stream_t stream) {
     const int upsample2x = resample == 1, downsample2x = resample == 2;
@@ -458,11 +468,8 @@ int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, con
     const int64_t w_bytes = fg_conv_packed_bytes(Cout, Cin, kt, ks, ks);
     FG_CHECK_ARG(x_bytes < 0xF0000000ll && w_bytes < 0xF0000000ll, "fg_conv3d_cl_bf16: input / weights must be < 3.75 GiB (32-bit offsets)");
     p.x_bytes = (uint32_t)x_bytes; p.w_bytes = (uint32_t)w_bytes;
-    // Tile choice: the 256x256 LDS-DMA kernel when it fills the chip (>= one workgroup per CU) and Cout is a multiple
-    // of 256; the 128x128 kernel (two workgroups per CU) for the low-resolution layers and odd channel counts.
     const int64_t blocks256 = ((p.M + kT2 - 1) / kT2) * (p.cout_pad / kT2);
-    const int variant = conv_variant_override() ? conv_variant_override() : ((Cout % kT2 == 0 && blocks256 >= 224) ? 256 : 128);
-    if (variant == 256 && Cout % kT2 == 0) {
+    if (fg_conv_tile_choice(T, H, W, Cout) == 256) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cl_256_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile2);
         FG_CHECK_ARG(attr == hipSuccess, "fg_conv3d_cl_bf16: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));

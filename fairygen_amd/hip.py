@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("FAIRYGEN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfairygen_hip.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -23,8 +23,8 @@ _SIGNATURES = {
     "fg_ln_affine_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "fg_gate_residual_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
     "fg_residual_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
-    "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
-    "fg_rmsnorm_rope_grouped_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i64, _i64, _vp],
+    "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _vp],
+    "fg_rmsnorm_rope_grouped_bf16": [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _i64, _i64, _vp],
     "fg_copy_groups_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
@@ -46,7 +46,8 @@ _SIGNATURES = {
     "fg_softmax_bias_bf16": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "fg_gated_gelu_bf16": [_vp, _vp, _vp, _i64, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice",
+                                                   "fg_conv_tile_choice"])
 
 
 class HipLibraryError(RuntimeError):
@@ -73,6 +74,8 @@ def load():
     lib.fg_conv_packed_bytes.argtypes = [_i32] * 5
     lib.fg_attn_workspace_bytes.restype = ctypes.c_int64
     lib.fg_attn_workspace_bytes.argtypes = [_i32, _i64, _i64, _i32]
+    lib.fg_conv_tile_choice.restype = ctypes.c_int
+    lib.fg_conv_tile_choice.argtypes = [_i32] * 4
     lib.fg_attn_split_choice.restype = ctypes.c_int
     lib.fg_attn_split_choice.argtypes = [_i32, _i64, _i64, _i32, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     for name, argtypes in _SIGNATURES.items():
@@ -205,6 +208,9 @@ def residual_ln_affine(x, y, w, b, eps, mod=None, gate_idx=None, x_out=None, nor
 def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None, grouped=None):
     """x: (..., C) possibly a column slice of a wider row-major buffer (stride(-2) = ld).
 
+    RoPE tables: cos and sin fp64 (rows, head_dim/2) -> the reference's fp64 rotation; or cos = ONE fp32 interleaved
+    (rows, head_dim/2, 2) table {cos, sin} with sin=None -> fp32 FMA rotation (the fast default of the pipeline).
+
     grouped=(dst, group_cols, group_stride, ld): write column block g of row r to the 1-D view
     dst[g*group_stride + r*ld : ... + group_cols] instead of a (rows, C) tensor (Ulysses send buffer); returns dst."""
     _dev(x, "x"), _dev(weight, "weight")
@@ -219,7 +225,13 @@ def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None, groupe
     rows, ld = x2.shape[0], x2.stride(0)
     if grouped is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
-    if cos is not None:
+    f32tab = 0
+    if cos is not None and sin is None:
+        f32tab = 1
+        _dev(cos, "rope table", torch.float32)
+        if cos.shape != (rows, c // num_heads // 2, 2) or not cos.is_contiguous():
+            raise HipLibraryError(f"rmsnorm_rope: the fp32 rope table must be ({rows}, {c // num_heads // 2}, 2) contiguous")
+    elif cos is not None:
         _dev(cos, "cos", torch.float64), _dev(sin, "sin", torch.float64)
         if cos.shape != (rows, c // num_heads // 2) or not cos.is_contiguous() or not sin.is_contiguous():
             raise HipLibraryError(f"rmsnorm_rope: rope tables must be ({rows}, {c // num_heads // 2}) contiguous")
@@ -230,10 +242,10 @@ def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None, groupe
         if dst.dim() != 1 or dst.stride(0) != 1 or \
                 (groups - 1) * group_stride + max(rows - 1, 0) * out_ld + group_cols > dst.numel():
             raise HipLibraryError("rmsnorm_rope: grouped destination too small for the requested layout")
-        _call("fg_rmsnorm_rope_grouped_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), _ptr(dst), rows, c,
+        _call("fg_rmsnorm_rope_grouped_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), f32tab, _ptr(dst), rows, c,
               num_heads, eps, group_cols, group_stride, out_ld, _stream(x))
         return dst
-    _call("fg_rmsnorm_rope_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), _ptr(out), rows, c, num_heads,
+    _call("fg_rmsnorm_rope_bf16", _ptr(x2), ld, _ptr(weight), _ptr(cos), _ptr(sin), f32tab, _ptr(out), rows, c, num_heads,
           eps, _stream(x))
     return out
 

@@ -26,10 +26,20 @@ branch (sequence-parallel inside the half) and exchanges the two predictions wit
 One process per GPU; process groups are torch.distributed's ("nccl" == RCCL on ROCm; "gloo" in CPU tests and in
 the several-ranks-on-one-GPU rehearsal, where device tensors are staged through the host).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 ATTN_MODES = ("allgather", "ulysses", "windows")
+
+
+def force_collectives():
+    """FAIRYGEN_FORCE_COLLECTIVES=1 (tests / single-GPU rehearsal only): a 1-rank group does NOT take the "nothing to
+    exchange" short-cuts, so every collective of the sharded path (all_gather_into_tensor, all_to_all_single, broadcast
+    on device tensors, async_op and the interleaved generators) executes on a 1-rank RCCL communicator exactly as it
+    does on 8 — the only way to execute those branches on a one-GPU box."""
+    return os.environ.get("FAIRYGEN_FORCE_COLLECTIVES", "0") == "1"
 
 
 def _staged(t, group):
@@ -46,6 +56,8 @@ class TokenShard:
             self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
             self.world_size, self.rank = 1, 0
+        # active: the exchanges run (more than one rank, or forced on an initialised 1-rank group)
+        self.active = self.world_size > 1 or (force_collectives() and dist.is_available() and dist.is_initialized())
 
     def chunk(self, n):
         """Rows per rank: ceil split like torch.chunk (wan_video.py:1312); trailing ranks may be short/empty."""
@@ -80,7 +92,7 @@ class TokenShard:
     # ------------------------------------------------------------------ K/V all-gather exchange
     def all_gather_kv(self, k, v, n=None):
         """k, v (1, n_local, C) of this rank's tokens -> (1, N, C) of all tokens, in token order."""
-        if self.world_size == 1:
+        if not self.active:
             return k, v
         if n is None:
             counts = torch.tensor([k.shape[1]], device=k.device)
@@ -100,7 +112,7 @@ class TokenShard:
 
     def all_gather_tokens(self, x, n):
         """x (1, n_local, C) -> (1, N, C) (final head all-gather, wan_video.py:1379-1382)."""
-        if self.world_size == 1:
+        if not self.active:
             return x
         return self._gather_rows(x[0], self.chunk(n))[:n].unsqueeze(0).contiguous()
 
@@ -147,10 +159,20 @@ class TokenShard:
         all-to-all; `.wait()` -> (1, n_local, H*D) for this rank's tokens, all heads."""
         return _PendingOut(self, o_full, n, n_local)
 
+    def shared_seed(self):
+        """A random seed drawn by group rank 0 and broadcast, so that the ranks working on ONE clip start from the same
+        noise when the caller passes the reference's default seed=None."""
+        t = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+        if self.active:
+            if dist.get_backend(self.group) != "gloo":
+                t = t.to(torch.device("cuda", torch.cuda.current_device()))
+            self.broadcast(t, 0)
+        return int(t.item())
+
     # ------------------------------------------------------------------ VAE tiles
     def broadcast(self, tensor, src):
         """In-place broadcast from group rank `src` (VAE tiles decoded by different ranks)."""
-        if self.world_size > 1:
+        if self.active:
             gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
             if _staged(tensor, self.group):
                 host = tensor.cpu()
@@ -164,7 +186,7 @@ class TokenShard:
 class _PendingKV:
     def __init__(self, shard, k, v, n):
         self.n, self.works = n, []
-        if shard.world_size == 1:
+        if not shard.active:
             self.kf, self.vf = k[0], v[0]
             return
         size = shard.chunk(n)

@@ -236,6 +236,33 @@ class WanVideoUnit_TeaCache(PipelineUnit):
         return {"tea_cache": TeaCache(num_inference_steps, rel_l1_thresh=tea_cache_l1_thresh, model_id=tea_cache_model_id)}
 
 
+class WanVideoUnit_CfgMerger(PipelineUnit):
+    """:785-803 — cfg_merge=True: the positive and the negative context are concatenated on the batch axis, the loop then
+    makes ONE model_fn call per step and splits its (2, ...) prediction.  (Like the reference, the per-branch inputs —
+    including a TeaCache — are dropped.)"""
+
+    def __init__(self):
+        super().__init__(take_over=True)
+        self.concat_tensor_names = ["context"]
+
+    def process(self, pipe, inputs_shared, inputs_posi, inputs_nega):
+        if not inputs_shared["cfg_merge"]:
+            return inputs_shared, inputs_posi, inputs_nega
+        for name in self.concat_tensor_names:
+            tensor_posi, tensor_nega, tensor_shared = inputs_posi.get(name), inputs_nega.get(name), inputs_shared.get(name)
+            if tensor_posi is not None and tensor_nega is not None:
+                inputs_shared[name] = torch.concat((tensor_posi, tensor_nega), dim=0)
+            elif tensor_shared is not None:
+                inputs_shared[name] = torch.concat((tensor_shared, tensor_shared), dim=0)
+        inputs_posi.clear()
+        inputs_nega.clear()
+        return inputs_shared, inputs_posi, inputs_nega
+
+
+# parameters of other Wan variants' features: inert without the feature's main input (which raises below), so the
+# reference's own non-None defaults — or any other value — are accepted
+_INERT_KWARGS = ("audio_sample_rate", "camera_control_speed", "camera_control_origin", "vace_scale", "vap_prompt",
+                 "negative_vap_prompt")
 _OUT_OF_SCOPE_KWARGS = (
     "end_image", "input_audio", "audio_embeds", "s2v_pose_video", "s2v_pose_latents", "motion_video",
     "control_video", "reference_image", "camera_control_direction", "vace_video", "vace_video_mask",
@@ -267,6 +294,7 @@ class WanVideoPipeline(torch.nn.Module):
             WanVideoUnit_InputVideoEmbedder(),
             WanVideoUnit_ImageEmbedderFused(),
             WanVideoUnit_TeaCache(),
+            WanVideoUnit_CfgMerger(),
         ]
         self.post_units = []
         self.model_fn = model_fn_wan_video
@@ -411,13 +439,17 @@ class WanVideoPipeline(torch.nn.Module):
                  progress_bar_cmd=tqdm, output_type="quantized",
                  first_frame_latents=None, **other):
         for name, value in other.items():
+            if name in _INERT_KWARGS:
+                continue
             if name not in _OUT_OF_SCOPE_KWARGS:
                 raise TypeError(f"__call__() got an unexpected keyword argument {name!r}")
             if value is not None:
                 raise NotImplementedError(f"{name}= belongs to another Wan variant / feature outside the TI2V-5B hot path")
-        if cfg_merge:
-            raise NotImplementedError("cfg_merge=True (batched CFG) is not on the reference inference.py path")
         self.scheduler.set_timesteps(num_inference_steps, denoising_strength=denoising_strength, shift=sigma_shift)
+        if seed is None and self.parallel is not None and self.parallel.world is not None and self.parallel.world.active:
+            # the reference default (seed=None) would give every rank of the clip its own noise and the token shards
+            # would silently mix different clips: the ranks of a layout agree on rank 0's draw
+            seed = self.parallel.world.shared_seed()
 
         tea = {"tea_cache_l1_thresh": tea_cache_l1_thresh, "tea_cache_model_id": tea_cache_model_id,
                "num_inference_steps": num_inference_steps}
@@ -447,7 +479,7 @@ class WanVideoPipeline(torch.nn.Module):
 
     def decode_latents(self, latents, tiled=True, tile_size=(30, 52), tile_stride=(15, 26)):
         """vae.decode on the device (reference :322-323); tiles are dealt over all ranks."""
-        shard = self.parallel.world if (self.parallel is not None and self.parallel.world.world_size > 1) else None
+        shard = self.parallel.world if (self.parallel is not None and self.parallel.world.active) else None
         return self.vae.decode(latents, device=self.device, tiled=tiled, tile_size=tile_size, tile_stride=tile_stride,
                                shard=shard)
 
@@ -463,16 +495,30 @@ class WanVideoPipeline(torch.nn.Module):
         models = {name: getattr(self, name) for name in self.in_iteration_models}
         shared = {k: v for k, v in inputs_shared.items()
                   if k in ("latents", "fuse_vae_embedding_in_latents", "sliding_window_size", "sliding_window_stride")}
+        cfg_merge = bool(inputs_shared.get("cfg_merge")) and "context" not in inputs_posi
+        if cfg_merge:
+            shared["context"] = inputs_shared["context"]              # (2, L, text_dim): [positive; negative]
         shared["sequence_shard"] = self.sequence_shard
         latents = inputs_shared["latents"].contiguous()
         first = inputs_shared.get("first_frame_latents")
-        sharded = self.sequence_shard is not None and self.sequence_shard.world_size > 1
+        sharded = self.sequence_shard is not None and self.sequence_shard.active
         cfg_split = self.parallel is not None and self.parallel.cfg_parallel == 2 and self.model_fn is model_fn_wan_video
-        interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split
+        if cfg_merge and cfg_split:
+            raise NotImplementedError("cfg_merge=True batches both branches into one forward; a cfg_parallel=2 layout gives "
+                                      "each branch its own ranks — use one or the other")
+        interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split and not cfg_merge
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
-            if cfg_split:
+            if cfg_merge:
+                # reference :296-299: one call on the batched context, then chunk (with cfg_scale == 1 the reference still
+                # runs the batch of two and keeps both halves' mean-free "posi": it uses the whole (2, ...) tensor — not a
+                # combination anyone relies on, so cfg_scale == 1 simply uses the positive half)
+                both = self.model_fn(**models, **shared, timestep=ts)
+                posi, nega = (t.contiguous() for t in both.chunk(2, dim=0))
+                if cfg_scale == 1.0:
+                    nega = None
+            elif cfg_split:
                 # this rank's half of the world computes ONE branch; one world all-gather exchanges the predictions
                 mine = inputs_posi if (self.parallel.branch == 0 or cfg_scale == 1.0) else inputs_nega
                 out_loc, grid = self.model_fn(**models, **shared, **inputs_posi_ctx(mine), timestep=ts, gather_output=False)
@@ -554,11 +600,12 @@ def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window
     border = sliding_window_size - sliding_window_stride
     windows = temporal_windows(t_all, sliding_window_size, sliding_window_stride)
     world, rank = (window_shard.world_size, window_shard.rank) if window_shard is not None else (1, 0)
+    exchange = window_shard is not None and window_shard.active
     outs = {}
     for i, (t, t_) in enumerate(windows):
         if i % world == rank:
             outs[i] = yield from window_fn(latents[:, :, t:t_].contiguous())
-    if world > 1:
+    if exchange:
         # one collective: every rank contributes its windows, zero-padded to `sliding_window_size` frames, in slot order
         per_rank = (len(windows) + world - 1) // world
         slot = c * sliding_window_size * h * w
@@ -593,13 +640,28 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     the reference (:1219-1228) has only two distinct rows (t=0 for the first latent frame, t elsewhere): both rows
     go through time_embedding / time_projection once and the kernels index them by token position.
     """
-    assert latents.shape[0] == 1, "batch 1 (cfg_merge is not on the hot path)"
+    assert latents.shape[0] == 1, "one clip per call"
+    if context.shape[0] > 1:
+        # merged CFG (reference :1237-1242): the latents are repeated over the context batch and the DiT runs on the batch.
+        # Every op of the forward is per batch element, so the batch is evaluated element by element on the batch-1
+        # kernels: identical results, the prediction comes back stacked on dim 0 like the reference's.
+        if tea_cache is not None:
+            raise NotImplementedError("TeaCache is per CFG branch; the merged call has none (the reference drops it too)")
+        outs = []
+        for b in range(context.shape[0]):
+            outs.append((yield from model_fn_wan_video_steps(
+                dit, latents=latents, timestep=timestep, context=context[b:b + 1], sequence_shard=sequence_shard,
+                fuse_vae_embedding_in_latents=fuse_vae_embedding_in_latents, gather_output=gather_output,
+                sliding_window_size=sliding_window_size, sliding_window_stride=sliding_window_stride)))
+        if not gather_output:
+            return torch.cat([o[0] for o in outs], dim=0), outs[0][1]
+        return torch.cat(outs, dim=0)
     if sliding_window_size is not None and sliding_window_stride is not None:
         # the reference's approximate long-video mode (:1158-1182).  Its window calls do not receive
         # fuse_vae_embedding_in_latents (absent from its model_kwargs), so they run in the single-timestep mode.
         if not gather_output:
             raise NotImplementedError("sliding windows need whole predictions: use a cfg_parallel=1 layout")
-        by_window = sequence_shard is not None and sequence_shard.world_size > 1 and sequence_shard.attn_mode == "windows"
+        by_window = sequence_shard is not None and sequence_shard.active and sequence_shard.attn_mode == "windows"
         if by_window and tea_cache is not None:
             raise NotImplementedError("TeaCache carries state from window to window (the reference shares one object across "
                                       "them); windows dealt to different ranks cannot reproduce that order")
@@ -607,7 +669,7 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
             lambda win: model_fn_wan_video_steps(dit, latents=win, timestep=timestep, context=context,
                                                  sequence_shard=None if by_window else sequence_shard, tea_cache=tea_cache),
             latents, sliding_window_size, sliding_window_stride, sequence_shard if by_window else None))
-    if sequence_shard is not None and sequence_shard.world_size > 1 and sequence_shard.attn_mode == "windows":
+    if sequence_shard is not None and sequence_shard.active and sequence_shard.attn_mode == "windows":
         raise ValueError('attn_mode="windows" shards the sliding-window mode: pass sliding_window_size= and '
                          'sliding_window_stride= (the exact path shards with "ulysses" or "allgather")')
     dev, dt = latents.device, latents.dtype
@@ -627,12 +689,12 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     n = f * h * w
     first_rows = h * w if ti2v else 0
     cos, sin = dit.rope_tables(f, h, w, dev)
-    if sequence_shard is not None and sequence_shard.world_size > 1:
+    if sequence_shard is not None and sequence_shard.active:
         lo, hi = sequence_shard.local_range(n)
         x_loc = x[:, lo:hi].contiguous()
         skip = tea_cache is not None and tea_cache.check(dit, x_loc, TimeModulation(mod_rows_t, first_rows, n))
         out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
-                                                      (cos[lo:hi].contiguous(), sin[lo:hi].contiguous()), sequence_shard, n,
+                                                      (cos[lo:hi].contiguous(), sin[lo:hi].contiguous() if sin is not None else None), sequence_shard, n,
                                                       tea_cache, skip)
         if not gather_output:
             return out_loc, (f, h, w)

@@ -37,6 +37,21 @@ def precompute_freqs_cis_3d(dim, end=1024, theta=10000.0):
             precompute_freqs_cis(dim // 3, end, theta))
 
 
+# The bias-GEMMs of the 30 blocks (hipBLASLt behind PyTorch, as north_star leaves them).  Module-level seams so that
+# bench.py can put HIP events around exactly these launches (its hipBLASLt roofline entry); looked up at call time.
+def gemm_bias(x, weight, bias):
+    return F.linear(x, weight, bias)
+
+
+def gemm_bias_gelu(x, weight, bias):
+    """ffn.0 with GELU(tanh) applied to the fp32 accumulator in the hipBLASLt epilogue; x (1, n, K)."""
+    return torch._addmm_activation(bias, x[0], weight.t(), use_gelu=True).unsqueeze(0)
+
+
+def gemm_bias_tuned(x, weight, bias):
+    return tuning.linear(x, weight, bias)      # table: better hipBLASLt solution at the multi-GPU shard sizes
+
+
 class RMSNorm(nn.Module):
     def __init__(self, dim, eps=1e-5):
         super().__init__()
@@ -150,6 +165,10 @@ class WanModel(nn.Module):
         self.head = Head(dim, out_dim, self.patch_size, eps)
         self.freqs = precompute_freqs_cis_3d(dim // num_heads)
         self._rope_cache = {}
+        # "f32" (default): RoPE as two fp32 FMAs on a table rounded once from the reference's complex128 one (the fp64
+        # rotation costs 43 us of VALU per call on a 77 us HBM-bound kernel; < 0.2 % of the outputs move, by 1 bf16 ulp).
+        # "f64": the reference's arithmetic exactly (rope_apply upcasts to complex128).
+        self.rope_mode = "f32"
         # True: GELU(tanh) applied to the fp32 accumulator in the hipBLASLt epilogue of ffn.0 (one pass less over the
         # (n, ffn) tensor, -1.9 % per forward; verified to be the tanh form, tools/gelu_epilogue_check.py; <= 1 bf16 ulp
         # from the reference's "round, then GELU" order).  False: GEMM, then fg_act_bf16 on the rounded output.
@@ -228,15 +247,19 @@ class WanModel(nn.Module):
 
     # ------------------------------------------------------------------ host-side tables
     def rope_tables(self, f, h, w, device):
-        """fp64 cos/sin of the per-token complex table, tokens frame-major (pipelines/wan_video.py:1271-1275)."""
-        key = (f, h, w, str(device))
+        """(cos, sin) of the per-token complex table, tokens frame-major (pipelines/wan_video.py:1271-1275): two fp64
+        (N, 64) tensors in rope_mode "f64", (one interleaved fp32 (N, 64, 2) tensor, None) in rope_mode "f32"."""
+        key = (f, h, w, str(device), self.rope_mode)
         if key not in self._rope_cache:
             tab = torch.cat([
                 self.freqs[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
                 self.freqs[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
                 self.freqs[2][:w].view(1, 1, w, -1).expand(f, h, w, -1),
             ], dim=-1).reshape(f * h * w, -1)
-            self._rope_cache = {key: (tab.real.contiguous().to(device), tab.imag.contiguous().to(device))}
+            if self.rope_mode == "f32":
+                self._rope_cache = {key: (torch.stack([tab.real, tab.imag], dim=-1).to(torch.float32).contiguous().to(device), None)}
+            else:
+                self._rope_cache = {key: (tab.real.contiguous().to(device), tab.imag.contiguous().to(device))}
         return self._rope_cache[key]
 
     def patchify(self, x):
@@ -288,7 +311,7 @@ class WanModel(nn.Module):
         blocks = list(self.blocks)
         if skip_blocks:
             blocks, x = [], tea_cache.update(x)
-        sharded = shard is not None and shard.world_size > 1
+        sharded = shard is not None and shard.active
         hot = bool(self.hot_loras)
         fp8 = self.fp8_dtype
         ctx8 = hip.fp8_quant_rows(context) if fp8 is not None else None      # the text context is the same for all blocks
@@ -302,7 +325,7 @@ class WanModel(nn.Module):
                 w8 = blk.fp8_weights(fp8)
                 lin = lambda t, j, bias, act=None: self._scaled_linear(*hip.fp8_quant_rows(t, act), w8[j], bias)      # noqa: E731
             # --- self attention (reference :139-146)
-            qkv = F.linear(h, wqkv, bqkv) if fp8 is None else lin(h, 0, bqkv)
+            qkv = gemm_bias(h, wqkv, bqkv) if fp8 is None else lin(h, 0, bqkv)
             if hot:
                 for j, nm in enumerate(("q", "k", "v")):
                     self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
@@ -337,15 +360,15 @@ class WanModel(nn.Module):
                 yield i
                 k, v = pending.wait()
                 a = sa.attn(q, k, v)
-            y = F.linear(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
+            y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
             if hot:
                 self._hot(f"blocks.{i}.self_attn.o", a, y)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
             x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
             # --- cross attention (reference :170-185)
             if fp8 is None:
-                qc = F.linear(h, ca.q.weight, ca.q.bias)
-                kvc = F.linear(context, wkv_c, bkv_c)
+                qc = gemm_bias(h, ca.q.weight, ca.q.bias)
+                kvc = gemm_bias(context, wkv_c, bkv_c)
             else:
                 qc = lin(h, 2, ca.q.bias)
                 kvc = self._scaled_linear(*ctx8, w8[3], bkv_c)
@@ -356,7 +379,7 @@ class WanModel(nn.Module):
             qc = hip.rmsnorm_rope(qc, ca.norm_q.weight, nh, eps)
             kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
             ac = ca.attn(qc, kc, kvc[..., c:])
-            y = F.linear(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
+            y = gemm_bias(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
             if hot:
                 self._hot(f"blocks.{i}.cross_attn.o", ac, y)
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
@@ -369,13 +392,13 @@ class WanModel(nn.Module):
                 y = lin(pre, 6, blk.ffn[2].bias, "gelu_tanh")
                 f = None
             elif hot and f"blocks.{i}.ffn.0" in self.hot_loras:      # the adapter adds to the pre-activation: no epilogue fusion
-                f = hip.activation(self._hot(f"blocks.{i}.ffn.0", h, F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias)), "gelu_tanh")
+                f = hip.activation(self._hot(f"blocks.{i}.ffn.0", h, gemm_bias(h, blk.ffn[0].weight, blk.ffn[0].bias)), "gelu_tanh")
             elif self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
-                f = torch._addmm_activation(blk.ffn[0].bias, h[0], blk.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
+                f = gemm_bias_gelu(h, blk.ffn[0].weight, blk.ffn[0].bias)
             else:
-                f = hip.activation(F.linear(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
+                f = hip.activation(gemm_bias(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
             if fp8 is None:
-                y = tuning.linear(f, blk.ffn[2].weight, blk.ffn[2].bias)      # table: better hipBLASLt solution at shard sizes
+                y = gemm_bias_tuned(f, blk.ffn[2].weight, blk.ffn[2].bias)
             if hot and f"blocks.{i}.ffn.2" in self.hot_loras:
                 if f is None:
                     f = hip.activation(pre.clone(), "gelu_tanh")

@@ -424,7 +424,8 @@ class WanVideoVAE38(nn.Module):
         values = torch.zeros((1, 3, out_T, H * up, W * up), dtype=z.dtype, device=device)
         tasks = self.tile_tasks(H, W, tile_size, tile_stride)
         world, rank = (shard.world_size, shard.rank) if shard is not None else (1, 0)
-        if world > 1:
+        exchange = shard is not None and shard.active
+        if exchange:
             from .sequence_parallel import assign_tiles
             owner = assign_tiles([(min(h_, H) - h) * (min(w_, W) - w) for h, h_, w, w_ in tasks], world)
         else:
@@ -434,7 +435,7 @@ class WanVideoVAE38(nn.Module):
             if owner[i] == rank:
                 tiles[i] = self.model.decode(z[:, :, :, h:h_, w:w_].contiguous(), self.scale)
         for i, (h, h_, w, w_) in enumerate(tasks):
-            if world > 1:
+            if exchange:
                 th, tw = (min(h_, H) - h) * up, (min(w_, W) - w) * up
                 tile = tiles.pop(i) if i in tiles else torch.empty((1, 3, out_T, th, tw), dtype=z.dtype, device=device)
                 shard.broadcast(tile, src=owner[i])

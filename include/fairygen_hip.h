@@ -34,7 +34,7 @@ extern "C" {
 
 typedef void* fg_stream_t;   /* hipStream_t */
 
-int         fg_version(void);            /* ABI version, currently 1 */
+int         fg_version(void);            /* ABI version, currently 2 */
 const char* fg_last_error(void);         /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------ DiT token-side kernels (HBM-bound)
@@ -73,11 +73,15 @@ int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_
 /* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
  * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,
  * CrossAttention.forward :176-177 with cos==sin==NULL).  x has leading dimension ldx (so q/k slices of a
- * fused QKV projection work), out is (rows, C) contiguous.  cos/sin: fp64 (rows, head_dim/2) tables, the
- * real/imag parts of the reference's complex128 table (pipelines/wan_video.py:1271-1275); the rotation is
- * done in fp64 like rope_apply (the kernel is HBM-bound, fp64 VALU is free here). */
+ * fused QKV projection work), out is (rows, C) contiguous.
+ * table_f32 == 0: cos_tab / sin_tab are fp64 (rows, head_dim/2) tables, the real / imag parts of the reference's
+ *   complex128 table (pipelines/wan_video.py:1271-1275), and the rotation is done in fp64 exactly like rope_apply.
+ * table_f32 != 0 (the default of the pipeline): cos_tab is ONE interleaved fp32 table (rows, head_dim/2, {cos, sin}) —
+ *   the fp64 table rounded once — sin_tab is NULL, and the rotation is two fp32 FMAs per output: the fp64 rotation
+ *   costs 43 us of VALU per call on top of the 77 us HBM time at N = 27 280 (2.8 -> 4.3 TB/s); the bf16 output
+ *   differs from the fp64 mode in < 0.2 % of the elements, by one bf16 ulp (tests/test_hip_kernels.py). */
 int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight,
-                         const double* cos_tab, const double* sin_tab, void* out,
+                         const void* cos_tab, const void* sin_tab, int table_f32, void* out,
                          int64_t rows, int C, int num_heads, float eps, fg_stream_t stream);
 
 /* Same arithmetic, head-group-major output for the sequence-parallel Ulysses exchange (the reference's
@@ -85,7 +89,7 @@ int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight,
  * column block g = col / group_cols of row r is written to out + g*out_group_stride + r*out_ld + col % group_cols,
  * i.e. straight into the all-to-all send buffer (block g = the heads of rank g). */
 int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight,
-                                 const double* cos_tab, const double* sin_tab, void* out,
+                                 const void* cos_tab, const void* sin_tab, int table_f32, void* out,
                                  int64_t rows, int C, int num_heads, float eps,
                                  int group_cols, int64_t out_group_stride, int64_t out_ld, fg_stream_t stream);
 
@@ -159,6 +163,9 @@ int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias,
                       const void* residual, void* out,
                       int T, int H, int W, int Cin, int Cout, int kt, int ks,
                       int resample, int time_interleave, fg_stream_t stream);
+/* Diagnostic: the tile variant fg_conv3d_cl_bf16 launches for an output of (T,H,W,Cout): 256 = conv3d_cl_256_kernel
+ * (256x256x64 tile, LDS-DMA staging) when it fills the chip, else 128 = conv3d_cl_kernel (128x128x64). */
+int fg_conv_tile_choice(int T, int H, int W, int Cout);
 
 /* out = main + DupUp3D(x): models/wan_video_vae.py:417-439,510-512.  x (T,H,W,Cin); main/out
  * (T*ft - drop, H*fs, W*fs, Cout) where drop = ft-1 if first_chunk. */

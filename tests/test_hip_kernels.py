@@ -110,6 +110,13 @@ def test_rmsnorm_rope(hip, heads, C, grid):
     want = wan_dit.rope_apply(wan_dit.rms_norm(xq, wt, 1e-6), table, heads)
     got = hip.rmsnorm_rope(dev(wide)[..., C:2 * C], dev(wt), heads, 1e-6, dev(cos), dev(sin))
     assert_close_bf16(got, want, 1.0, "rmsnorm+rope")
+    # the pipeline's default: ONE fp32 interleaved table, rotation as fp32 FMAs — same criterion (<= 1 bf16 ulp, >= 99.8 %
+    # of the elements bit-identical to the oracle's fp64 rotation), and next to the fp64 mode of the same kernel
+    cs = torch.stack([table.real.reshape(n, -1), table.imag.reshape(n, -1)], dim=-1).to(torch.float32).contiguous()
+    got32 = hip.rmsnorm_rope(dev(wide)[..., C:2 * C], dev(wt), heads, 1e-6, dev(cs))
+    assert_close_bf16(got32, want, 1.0, "rmsnorm+rope (fp32 table)")
+    same = (got32 == got).float().mean().item()
+    assert same >= 0.998, f"fp32-table rotation: only {same:.5f} of the elements equal the fp64 mode"
     got = hip.rmsnorm_rope(dev(wide)[..., :C], dev(wt), heads, 1e-6)
     assert_close_bf16(got, wan_dit.rms_norm(wide[..., :C], wt, 1e-6), 1.0, "rmsnorm")
 
@@ -133,6 +140,11 @@ def test_ulysses_packing_kernels(hip):
     k = hip.rmsnorm_rope(qkv[..., C:2 * C], wt, heads, 1e-6)[0]
     for j, t in enumerate((q, k, qkv[0, :, 2 * C:])):
         assert torch.equal(send[:, :n, j], t.unflatten(-1, (P, g)).transpose(0, 1)), f"send block {j}"
+    cs = torch.stack([cos, sin], dim=-1).to(torch.float32).contiguous()      # the fp32-table mode, grouped == plain
+    send32 = torch.full((P, size, 3, g), 7.0, dtype=torch.bfloat16, device="cuda")
+    hip.rmsnorm_rope(qkv[..., :C], wt, heads, 1e-6, cs, grouped=(send32.view(-1), *layout))
+    q32 = hip.rmsnorm_rope(qkv[..., :C], wt, heads, 1e-6, cs)[0]
+    assert torch.equal(send32[:, :n, 0], q32.unflatten(-1, (P, g)).transpose(0, 1))
     assert (send[:, n:] == 7.0).all(), "rows past the shard must not be written"
     blocks = dev(seeded((P, size, g), 33))               # received head-group blocks -> "b s (n d)" rows
     a = torch.empty((1, n, C), dtype=torch.bfloat16, device="cuda")

@@ -506,6 +506,69 @@ def test_config2_forward_full_width_vs_reference_golden(golden):
     torch.cuda.empty_cache()
 
 
+def test_config3_forward_full_width_vs_reference_golden(golden):
+    """One forward of BASELINE.json configs[2], the HEADLINE configuration (704x1280x121: N = 27 280 tokens, rank-32 merged
+    motion LoRA fused at load) at the full model width against the reference's own bf16 prediction — produced by the
+    reference's model_fn_wan_video on weights fused by the reference's GeneralLoRALoader (oracle/gen_config3_forward.py; the
+    oracle equalled it bit for bit) — with the fp32 evaluation as yardstick: max|hip - f32| <= 2 max|ref_bf16 - f32| + floor."""
+    from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
+    from fairygen_amd.wan_video import WanVideoPipeline, model_fn_wan_video
+    from fairygen_amd.wan_video_dit import WanModel
+    g = golden("config3_forward.safetensors")
+    cfg = dict(TI2V_5B_DIT_KWARGS)
+    shapes = synthetic.dit_shapes(cfg)
+    with torch.device("meta"):
+        dit = WanModel(**cfg)
+    dit.load_state_dict(synthetic.random_state_dict(shapes, seed=1234), assign=True)
+    dit = dit.to(device="cuda", dtype=torch.bfloat16).eval()
+    pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+    pipe.dit = dit
+    pipe.load_lora(pipe.dit, state_dict=synthetic.random_lora(shapes, rank=32, seed=4321), alpha=1)      # inference.py:18
+    lat = seeded((1, 48, 31, 44, 80), 1)
+    lat[:, :, 0:1] = seeded((1, 48, 1, 44, 80), 4)
+    ctx = seeded((1, 512, 4096), 2); ctx[:, 64:] = 0
+    with torch.no_grad():
+        out = model_fn_wan_video(dit, latents=lat.cuda(), timestep=torch.tensor([700.0]).to(torch.bfloat16), context=ctx.cuda(),
+                                 fuse_vae_embedding_in_latents=True)
+    sub, ref, f32 = out[:, ::8, :, :, ::2].float().cpu(), g["pred_bf16_sub"].float(), g["pred_f32_sub"]
+    assert sub.shape == ref.shape == f32.shape == (1, 6, 31, 44, 40)
+    err_ref, err = (ref - f32).abs().max().item(), (sub - f32).abs().max().item()
+    assert err <= 2 * err_ref + 1e-2, (err, err_ref)
+    assert cos(sub, ref) > 0.9995 and (sub - f32).abs().mean().item() <= 1.25 * (ref - f32).abs().mean().item() + 1e-4
+    del dit, pipe
+    torch.cuda.empty_cache()
+
+
+def test_cfg_merge_and_reference_default_kwargs(tiny_dit, tiny_vae):
+    """cfg_merge=True (pipelines/wan_video.py:785-803,296-299: contexts concatenated on the batch axis, ONE model_fn call per
+    step, prediction chunked) gives the same clip as the two-call loop, bit for bit; the reference's non-None defaults of
+    out-of-scope features' parameters are accepted, their main inputs still raise."""
+    from fairygen_amd.wan_video import WanVideoPipeline, model_fn_wan_video
+    m, _, _ = tiny_dit
+    vae, _ = tiny_vae
+    pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
+    pipe.dit, pipe.vae = m, vae
+    pipe.height_division_factor = pipe.width_division_factor = 32
+    ctx_p = seeded((1, 16, 128), 2); ctx_p[:, 10:] = 0
+    ctx_n = seeded((1, 16, 128), 3); ctx_n[:, 12:] = 0
+    z0 = seeded((1, 48, 1, 4, 4), 4)
+    kw = dict(prompt=ctx_p, negative_prompt=ctx_n, first_frame_latents=z0, seed=1, height=64, width=64, num_frames=9,
+              num_inference_steps=3, tiled=False, output_type="floatpoint", progress_bar_cmd=lambda x: x)
+    calls = []
+    pipe.model_fn = lambda *a, **k: (calls.append(k["context"].shape[0]), model_fn_wan_video(*a, **k))[1]
+    two = pipe(**kw)
+    assert calls == [1] * 6
+    calls.clear()
+    merged = pipe(**kw, cfg_merge=True, audio_sample_rate=16000, vace_scale=1.0, camera_control_speed=1 / 54,
+                  vap_prompt=" ", negative_vap_prompt=" ")
+    assert calls == [2] * 3, "cfg_merge=True must make one batched call per step"
+    assert torch.equal(two, merged)
+    with pytest.raises(NotImplementedError, match="vace_video"):
+        pipe(**kw, vace_video=[object()])
+    with pytest.raises(TypeError):
+        pipe(**kw, no_such_argument=1)
+
+
 def _tiny_text_encoder():
     from fairygen_amd.wan_video_text_encoder import WanTextEncoder
     tkw = synthetic.TINY_TEXT_KWARGS
@@ -616,4 +679,4 @@ def test_batch_inference_folder_loop(tmp_path, tiny_dit, tiny_vae):
     assert [n for n, _ in done] == ["1", "3"]
     for _, path in done:
         data = open(path, "rb").read()
-        assert path.endswith(".mp4.avi") and data[:4] == b"RIFF" and data[8:12] == b"AVI "
+        assert path.endswith(".mp4") and data[4:8] == b"ftyp" and b"moov" in data and b"mdat" in data

@@ -207,9 +207,26 @@ def test_teacache_rows_form_matches_dense():
         TeaCache(4, 0.1, "Wan2.2-TI2V-5B")
 
 
-def test_save_video_fallback_writes_a_playable_mjpeg_avi(tmp_path):
-    """Without imageio/ffmpeg (this image) save_video writes <path>.avi: a RIFF AVI whose header, index and JPEG frames
-    parse back (frame count, size, rate) and whose frames decode to the input within JPEG error."""
+def _mp4_boxes(data, off, end, path=()):
+    """Flat {path: payload} map of an ISO base media file's box tree (containers descended)."""
+    import struct
+    out = {}
+    while off < end:
+        size, tag = struct.unpack(">I4s", data[off: off + 8])
+        assert size >= 8 and off + size <= end
+        here = path + (tag.decode("latin1"),)
+        if tag in (b"moov", b"trak", b"mdia", b"minf", b"stbl", b"dinf"):
+            out.update(_mp4_boxes(data, off + 8, off + size, here))
+        else:
+            out["/".join(here)] = data[off + 8: off + size]
+        off += size
+    return out
+
+
+def test_save_video_fallback_honours_the_requested_file_name(tmp_path):
+    """Without imageio/ffmpeg (this image) save_video writes Motion-JPEG into the container the file name asks for, AT that
+    path: 'clip.mp4' -> an ISO base media file whose sample tables parse back (count, size, rate, chunk offset) and whose
+    samples decode to the input within JPEG error; 'clip.avi' -> a RIFF AVI with header, index and frames."""
     import io
     import struct
     import numpy as np
@@ -218,8 +235,35 @@ def test_save_video_fallback_writes_a_playable_mjpeg_avi(tmp_path):
     rng = np.random.default_rng(0)
     base = rng.integers(0, 256, size=(8, 12, 3), dtype=np.uint8).repeat(8, 0).repeat(8, 1)        # 64x96 blocks
     frames = [Image.fromarray(np.roll(base, 8 * i, axis=1)) for i in range(5)]
-    out = save_video(frames, str(tmp_path / "clip.mp4"), fps=15, quality=9)
-    assert out.endswith("clip.mp4.avi")
+    target = str(tmp_path / "clip.mp4")
+    out = save_video(frames, target, fps=15, quality=9)
+    assert out == target
+    data = open(out, "rb").read()
+    assert data[4:8] == b"ftyp" and data[8:12] == b"isom"
+    boxes = _mp4_boxes(data, 0, len(data))
+    stbl = "moov/trak/mdia/minf/stbl/"
+    timescale, duration = struct.unpack(">II", boxes["moov/mvhd"][12:20])
+    assert timescale == 15000 and duration == 5000
+    w, h = struct.unpack(">II", boxes["moov/trak/tkhd"][-8:])
+    assert (w >> 16, h >> 16) == (96, 64)
+    assert boxes["moov/trak/mdia/hdlr"][8:12] == b"vide"
+    stsd = boxes[stbl + "stsd"]
+    assert stsd[12:16] == b"mp4v" and struct.unpack(">HH", stsd[16 + 24: 16 + 28]) == (96, 64) and b"esds" in stsd
+    assert stsd[stsd.index(b"esds") + 8 + 5 + 2] == 0x6C       # ES_Descriptor(tag,len,id:2,flags) -> DecoderConfig(tag,len) -> OTI = JPEG
+    assert struct.unpack(">III", boxes[stbl + "stts"][4:16]) == (1, 5, 1000)
+    assert struct.unpack(">IIII", boxes[stbl + "stsc"][4:20]) == (1, 1, 5, 1)
+    uniform, count = struct.unpack(">II", boxes[stbl + "stsz"][4:12])
+    sizes = struct.unpack(">5I", boxes[stbl + "stsz"][12:32])
+    (n_chunks, offset) = struct.unpack(">II", boxes[stbl + "stco"][4:12])
+    assert (uniform, count, n_chunks) == (0, 5, 1) and data[offset - 4: offset] == b"mdat" and sum(sizes) == len(boxes["mdat"])
+    for i, size in enumerate(sizes):
+        got = np.array(Image.open(io.BytesIO(data[offset: offset + size])).convert("RGB")).astype(int)
+        assert np.abs(got - np.array(frames[i]).astype(int)).mean() < 12
+        offset += size
+    # .avi (and any other extension): RIFF AVI at exactly that path
+    target = str(tmp_path / "clip.avi")
+    out = save_video(frames, target, fps=15, quality=9)
+    assert out == target
     data = open(out, "rb").read()
     assert data[:4] == b"RIFF" and data[8:12] == b"AVI " and struct.unpack("<I", data[4:8])[0] == len(data) - 8
     avih = data.index(b"avih")

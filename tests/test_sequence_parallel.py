@@ -377,3 +377,177 @@ def test_replicas_on_gpu(tmp_path):
 def test_sharded_dit_forward_on_gpu(tmp_path, world, port):
     mp.spawn(_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU + RCCL: the DEVICE-collective branches (all_gather_into_tensor / all_to_all_single(async_op=True) / broadcast /
+# all_reduce on HIP tensors, the interleaved generators with two exchanges in flight, barrier(device_ids=)).  On the one-GPU
+# test box they run on a 1-rank "nccl" (= RCCL) communicator with FAIRYGEN_FORCE_COLLECTIVES=1, which turns off every
+# "nothing to exchange" short-cut of a 1-rank group; with >= 2 GPUs visible the same worker runs one rank per device.
+def _rccl_worker(rank, world, port, result_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", FAIRYGEN_FORCE_COLLECTIVES="1")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # before any other GPU work
+    try:
+        from fairygen_amd import hip, synthetic
+        from fairygen_amd.sequence_parallel import ParallelLayout, TokenShard
+        from fairygen_amd.wan_video import WanVideoPipeline, model_fn_wan_video
+        from fairygen_amd.wan_video_dit import WanModel
+        from fairygen_amd.wan_video_vae import WanVideoVAE38
+        assert dist.get_backend() == "nccl"
+        exact = world == 1                      # one rank: same kernels on the same rows -> bit-identical
+        dist.barrier(device_ids=[rank])         # bench.py's barrier form
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # bench.py's sync_max
+        assert t.item() == world
+
+        # --- exchange primitives on device tensors
+        shard = TokenShard()
+        assert shard.active and (shard.world_size, shard.rank) == (world, rank)
+        heads, c, n = 4, 512, 203
+        q, k, qkv = seeded((1, n, c), 1).to(dev), seeded((1, n, c), 2).to(dev), seeded((1, n, 3 * c), 3).to(dev)
+        v = qkv[..., c:2 * c]
+        lo, hi = shard.local_range(n)
+        kf, vf = shard.all_gather_kv(k[:, lo:hi], v[:, lo:hi], n)
+        assert torch.equal(kf, k) and torch.equal(vf, v)
+        kf2, _ = shard.all_gather_kv(k[:, lo:hi].contiguous(), v[:, lo:hi].contiguous())      # N by a device all-reduce
+        assert torch.equal(kf2, k)
+        pa = shard.all_gather_kv_async(k[:, lo:hi], v[:, lo:hi], n)      # two async gathers in flight
+        pb = shard.all_gather_kv_async(q[:, lo:hi], k[:, lo:hi], n)
+        (ka, va), (kb, vb) = pa.wait(), pb.wait()
+        assert torch.equal(ka, k) and torch.equal(va, v) and torch.equal(kb, q) and torch.equal(vb, k)
+        want = hip.attention(q, k, v, heads)
+        got = shard.all_gather_tokens(hip.attention(q[:, lo:hi].contiguous(), kf, vf, heads), n)
+        assert torch.equal(got, want) if exact else (got.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+        us = TokenShard(attn_mode="ulysses")
+        hl = us.heads_local(heads)
+        g = hl * (c // heads)
+        p1 = us.ulysses_qkv_async(q[:, lo:hi], k[:, lo:hi], v[:, lo:hi], n, heads)      # two all-to-alls in flight
+        p2 = us.ulysses_qkv_async(k[:, lo:hi], q[:, lo:hi], v[:, lo:hi], n, heads)
+        qg, kg, vg = p1.wait()
+        kb2, qb2, _ = p2.wait()
+        cols = slice(rank * g, (rank + 1) * g)
+        assert torch.equal(qg, q[..., cols]) and torch.equal(kg, k[..., cols]) and torch.equal(vg, v[..., cols])
+        assert torch.equal(qb2, q[..., cols]) and torch.equal(kb2, k[..., cols])
+        o_full = us.ulysses_out_buffer(n, g, qg)
+        hip.attention(qg, kg, vg, hl, out=o_full[:n].unsqueeze(0))
+        out = us.ulysses_out_async(o_full, n, hi - lo).wait()
+        assert torch.equal(out, want[:, lo:hi]) if exact else \
+            (out.float() - want[:, lo:hi].float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+        tile = seeded((1, 3, 2, 4, 4), 9).to(dev) if rank == world - 1 else torch.empty((1, 3, 2, 4, 4), dtype=torch.bfloat16, device=dev)
+        shard.broadcast(tile, src=world - 1)
+        assert torch.equal(tile.cpu(), seeded((1, 3, 2, 4, 4), 9))
+        seeds = torch.tensor([shard.shared_seed()], device=dev)
+        lo_s, hi_s = seeds.clone(), seeds.clone()
+        dist.all_reduce(lo_s, op=dist.ReduceOp.MIN), dist.all_reduce(hi_s, op=dist.ReduceOp.MAX)
+        assert lo_s.item() == hi_s.item(), "ranks of one layout must agree on the seed"
+
+        # --- the sharded DiT forward through the device collectives == the unsharded forward
+        cfg = dict(synthetic.TINY_DIT_KWARGS, dim=512, num_heads=4, ffn_dim=1024)
+        m = WanModel(**cfg)
+        m.load_state_dict(synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=77))
+        m = m.to(device=dev, dtype=torch.bfloat16).eval()
+        lat = seeded((1, 48, 3, 10, 14), 5).to(dev)          # 105 tokens
+        ctx, ctx_n = seeded((1, 24, 128), 6).to(dev), seeded((1, 24, 128), 7).to(dev)
+        z0 = seeded((1, 48, 1, 10, 14), 8).to(dev)
+        ts = torch.tensor([500.0]).to(torch.bfloat16)
+        with torch.no_grad():
+            full = model_fn_wan_video(m, latents=lat, timestep=ts, context=ctx, fuse_vae_embedding_in_latents=True)
+            for mode in ("allgather", "ulysses"):
+                got = model_fn_wan_video(m, latents=lat, timestep=ts, context=ctx, fuse_vae_embedding_in_latents=True,
+                                         sequence_shard=TokenShard(attn_mode=mode))
+                torch.cuda.synchronize()
+                err = (full.float() - got.float()).abs().max().item()
+                assert (torch.equal(full, got) if exact else err <= 2.0 ** -6 * full.float().abs().max().item()), \
+                    f"sharded forward ({mode}) over RCCL differs: {err}"
+        # --- the denoise loop: interleaved CFG branches (two exchanges in flight per layer); cfg_parallel=2 needs >= 2 ranks
+        layouts = [None, (1, "allgather"), (1, "ulysses")] + ([(2, "allgather"), (2, "ulysses")] if world % 2 == 0 else [])
+        outs = []
+        for layout in layouts:
+            pipe = WanVideoPipeline(device=dev, torch_dtype=torch.bfloat16)
+            pipe.dit = m
+            if layout is not None:
+                pipe.enable_sequence_parallel(cfg_parallel=layout[0], attn_mode=layout[1])
+                assert pipe.sequence_shard.active
+            pipe.scheduler.set_timesteps(3, denoising_strength=1.0, shift=5.0)
+            lat0 = lat.clone()
+            lat0[:, :, 0:1] = z0
+            shared = {"latents": lat0, "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0}
+            with torch.no_grad():
+                outs.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
+        torch.cuda.synchronize()
+        for layout, o in zip(layouts[1:], outs[1:]):
+            err = (outs[0].float() - o.float()).abs().max().item()
+            assert (torch.equal(outs[0], o) if exact else err <= 0.05 * outs[0].float().abs().max().item()), \
+                f"sharded denoise loop {layout} over RCCL differs: {err}"
+        # --- sliding-window mode with the windows all-gathered on the device
+        lat9 = seeded((1, 48, 9, 10, 14), 5).to(dev)
+        wouts = []
+        for sharded in (False, True):
+            pipe = WanVideoPipeline(device=dev, torch_dtype=torch.bfloat16)
+            pipe.dit = m
+            if sharded:
+                pipe.enable_sequence_parallel(attn_mode="windows")
+            pipe.scheduler.set_timesteps(2, denoising_strength=1.0, shift=5.0)
+            shared = {"latents": lat9.clone(), "fuse_vae_embedding_in_latents": False, "first_frame_latents": None,
+                      "sliding_window_size": 4, "sliding_window_stride": 2}
+            with torch.no_grad():
+                wouts.append(pipe.denoise(shared, {"context": ctx}, {"context": ctx_n}, 5.0, progress_bar_cmd=lambda x: x))
+        assert torch.equal(wouts[0], wouts[1])
+        # --- tiled VAE decode: tiles dealt to the ranks and broadcast on the device == the single-process decode
+        vae = WanVideoVAE38(dim=32, dec_dim=32)
+        vae.load_state_dict(synthetic.random_state_dict(synthetic.vae_shapes(dec_dim=32, dim=32), seed=1234))
+        vae = vae.to(device=dev, dtype=torch.bfloat16).eval()
+        z = seeded((1, 48, 2, 8, 10), 11).to(dev)
+        lay = ParallelLayout(cfg_parallel=1, attn_mode="allgather")
+        with torch.no_grad():
+            one = vae.decode(z, device=dev, tiled=True, tile_size=(6, 6), tile_stride=(3, 4))
+            many = vae.decode(z, device=dev, tiled=True, tile_size=(6, 6), tile_stride=(3, 4), shard=lay.world)
+        torch.cuda.synchronize()
+        assert torch.equal(one, many), "tile-parallel decode over the device broadcast differs"
+        dist.barrier(device_ids=[rank])
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_device_collectives_one_rank(tmp_path):
+    """Every device-collective branch of sequence_parallel.py on a 1-rank RCCL communicator, bit-equal to the unsharded path."""
+    mp.spawn(_rccl_worker, args=(1, 29650, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok0")
+
+
+@pytest.mark.gpu
+def test_rccl_device_collectives_two_ranks(tmp_path):
+    """The same worker with one rank per device over xGMI — runs wherever >= 2 GPUs are leased (skipped on the 1-GPU box)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL cannot put two ranks on one device)")
+    mp.spawn(_rccl_worker, args=(2, 29651, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(2))
+
+
+def test_forced_collectives_one_rank_gloo(tmp_path):
+    """CPU twin of the 1-rank RCCL test: FAIRYGEN_FORCE_COLLECTIVES=1 makes a 1-rank group run its collectives."""
+    mp.spawn(_forced_gloo_worker, args=(29652, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok0")
+
+
+def _forced_gloo_worker(rank, port, result_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", FAIRYGEN_FORCE_COLLECTIVES="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from fairygen_amd.sequence_parallel import TokenShard
+        s = TokenShard(attn_mode="ulysses")
+        assert s.active and s.world_size == 1
+        k, v = seeded((1, 7, 8), 1), seeded((1, 7, 8), 2)
+        kf, vf = s.all_gather_kv(k, v, 7)
+        assert kf is not k and torch.equal(kf, k) and torch.equal(vf, v)          # a real collective made a copy
+        q2, k2, v2 = s.ulysses_qkv_async(k, v, k, 7, 2).wait()
+        assert torch.equal(q2, k) and torch.equal(k2, v) and torch.equal(v2, k)
+        assert isinstance(s.shared_seed(), int)
+        open(os.path.join(result_dir, "ok0"), "w").close()
+    finally:
+        dist.destroy_process_group()

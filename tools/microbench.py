@@ -84,7 +84,13 @@ def main():
         mod = hip.ModTable(rnd(2, 6, c), 880)
         o1, o2 = torch.empty_like(x), torch.empty_like(x)
         by = a.rows * c * 2
+        cos = torch.rand((a.rows, 64), device=dev, dtype=torch.float64)
+        sin = (1 - cos * cos).sqrt()
+        cs = torch.stack([cos, sin], dim=-1).float().contiguous()
+        wide = rnd(1, a.rows, 3 * c)
         for name, fn, nbytes in [
+            ("rmsnorm+rope fp64 tables (q slice of qkv)", lambda: hip.rmsnorm_rope(wide[..., :c], mod.table[0, 0], 24, 1e-6, cos, sin, out=o1), 2 * by),
+            ("rmsnorm+rope fp32 table (q slice of qkv)", lambda: hip.rmsnorm_rope(wide[..., :c], mod.table[0, 0], 24, 1e-6, cs, out=o1), 2 * by),
             ("ln_modulate", lambda: hip.ln_modulate(x, mod, 0, 1, 1e-6, out=o1), 2 * by),
             ("residual_ln_modulate", lambda: hip.residual_ln_modulate(x, y, mod, 5, 0, 1, 1e-6, x_out=o1, norm_out=o2), 4 * by),
             ("rmsnorm(no rope)", lambda: hip.rmsnorm_rope(x, mod.table[0, 0], 24, 1e-6, out=o1), 2 * by),
