@@ -24,7 +24,8 @@ import sys
 
 THR = 6.0          # deferred rescale threshold (log2 units), same as kDeferLog2 of the HIP kernel
 NVW = 8            # V^T fragment window (slots of 4 VGPRs)
-GAP_BUDGET = 24    # issue-cost units a gap can hide besides its MFMA (guide: MFMA holds issue for 8 of its 32 cycles)
+DMA_COST, DMA_EVERY = 16, 3   # scheduler cost of one LDS-DMA piece (3 instructions) and the gap distance between pieces
+GAP_BUDGET = 18    # issue-cost units a gap can hide besides its MFMA (guide: MFMA holds issue for 8 of its 32 cycles)
 K_LDS, V_LDS, TILE = 0, 65536, 16384
 
 # ---------------------------------------------------------------- register map
@@ -55,7 +56,7 @@ SBASE = 40          # SGPRs SBASE .. SBASE+47 are owned by the asm body (clobber
 S = {k: v + SBASE for k, v in dict(
     QD=0, KD=4, VD=8, OD=12, MLD=16, WAVE=20, KSTR=21, VSTR=22, SCALE=23, T=24, TEND=25, TRAG=26, NVALID=27,
     LDQ=28, LDK=29, LDV=30, OROW=31, QROW0=32, PIECE=33, KDST=34, VDST=35, INVSCALE=36, TMP0=37, TMP1=38, TMP2=39,
-    TMP64=40, SAVE64=42, NEXT=44, ARGS=48).items()}
+    TMP64=40, SAVE64=42, NEXT=44, TENDM2=45, ARGS=48).items()}
 NSREG = 60
 
 def vr(lo, n=1):
@@ -90,7 +91,8 @@ class Item:
         self.lds, self.trans = lds, trans          # lds: number of LDS return values this item issues (lgkmcnt tracking)
         self.gap = None
 
-def schedule(items, ngaps, budget=GAP_BUDGET):
+def schedule(items, ngaps, budget=None):
+    budget = GAP_BUDGET if budget is None else budget
     load = [0] * ngaps
     ntrans = [0] * ngaps
     out = [[] for _ in range(ngaps)]
@@ -211,7 +213,8 @@ def emit_lane_setup(E):
     E.e(f"v_lshlrev_b32 {vr(T1)}, 4, {vr(T1)}")
     E.e(f"v_mul_lo_u32 {vr(T0)}, {vr(T0)}, {sr(S['LDK'])}")
     E.e(f"v_add_u32 {vr(T0)}, {vr(T0)}, {vr(T1)}")
-    E.e(f"s_mul_i32 {sr(S['TMP1'])}, {sr(S['T'])}, {sr(S['KSTR'])}")
+    E.e(f"s_sub_u32 {sr(S['TMP1'])}, {sr(S['T'])}, 1")                   # pre-increment form: one tile behind (wraps for t = 0)
+    E.e(f"s_mul_i32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {sr(S['KSTR'])}")
     E.e(f"v_add_u32 {vr(V_DK)}, {sr(S['TMP1'])}, {vr(T0)}")
     E.e(f"s_lshl_b32 {sr(S['TMP2'])}, {sr(S['LDK'])}, 4")                # 16 rows
     for i in range(1, 4):
@@ -233,7 +236,8 @@ def emit_lane_setup(E):
     E.e(f"v_lshlrev_b32 {vr(T1)}, 4, {vr(T1)}")
     E.e(f"v_mul_lo_u32 {vr(T0)}, {vr(T0)}, {sr(S['LDV'])}")
     E.e(f"v_add_u32 {vr(T0)}, {vr(T0)}, {vr(T1)}")
-    E.e(f"s_mul_i32 {sr(S['TMP1'])}, {sr(S['T'])}, {sr(S['VSTR'])}")
+    E.e(f"s_sub_u32 {sr(S['TMP1'])}, {sr(S['T'])}, 1")
+    E.e(f"s_mul_i32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {sr(S['VSTR'])}")
     E.e(f"v_add_u32 {vr(V_DV)}, {sr(S['TMP1'])}, {vr(T0)}")
     E.e(f"s_lshl_b32 {sr(S['TMP2'])}, {sr(S['LDV'])}, 4")
     for i in range(1, 4):
@@ -259,22 +263,18 @@ def emit_lane_setup(E):
 
 
 def dma_lines(kind, i, slot):
-    """One LDS-DMA piece: advance nothing here (the caller advances the source offsets once per tile)."""
-    base, dst, rs = (V_DK, S["KDST"], S["KD"]) if kind == "K" else (V_DV, S["VDST"], S["VD"])
+    """One LDS-DMA piece, pre-increment form: the source offset register holds the PREVIOUS tile's offset and is advanced by
+    one tile right before its load; the advance also separates the M0 write from the load that reads M0 (one wait state)."""
+    base, dst, rs, st = (V_DK, S["KDST"], S["KD"], S["KSTR"]) if kind == "K" else (V_DV, S["VDST"], S["VD"], S["VSTR"])
     return [f"s_add_u32 m0, {sr(dst)}, {slot * TILE + i * 4096}",
-            f"s_nop 0",
+            f"v_add_u32 {vr(base + i)}, {sr(st)}, {vr(base + i)}",
             f"buffer_load_dwordx4 {vr(base + i)}, {sr(rs, 4)}, 0 offen lds"]
-
-def dma_advance(kind, i):
-    base, st = (V_DK, S["KSTR"]) if kind == "K" else (V_DV, S["VSTR"])
-    return f"v_add_u32 {vr(base + i)}, {sr(st)}, {vr(base + i)}"
 
 
 def emit_issue_tile(E, kind, slot):
     for i in range(4):
         for ln in dma_lines(kind, i, slot):
             E.e(ln)
-        E.e(dma_advance(kind, i))
 
 
 def mfma_qk(buf, qi, sub, ks, first_c):
@@ -362,17 +362,21 @@ def emit_mask_block(E, buf_next, ret_label):
     E.e(f"s_branch {ret_label}")
 
 
-def build_step(E, phase, prescale, cold):
-    """One pipeline step t with t & 3 == phase.  sc = scores of tile t (buffer phase & 1), sn <- scores of tile t+1.
-    `cold` collects out-of-line blocks (label, emitter function)."""
+def build_step(E, phase, prescale, cold, flagged):
+    """One pipeline step t with (t - t_begin) & 3 == phase.  sc = scores of tile t (buffer phase & 1), sn <- scores of tile t+1.
+    flagged: the copy used for the last two steps of a range (tile t+1 may be the ragged last tile, or absent: S[NEXT]);
+    the plain copy assumes an ordinary next tile.  `cold` collects out-of-line blocks (label, emitter function)."""
     cur, nxt = phase & 1, (phase & 1) ^ 1
     slot_v = phase                      # V(t) ring slot
-    slot_k2 = (phase + 2) & 3           # K(t+2): fragment reads in phase B
+    slot_k2 = (phase + 2) & 3           # K(t+2): fragment reads
     slot_kd = phase                     # K(t+4) DMA destination
     slot_vd = (phase + 3) & 3           # V(t+3) DMA destination
     items = []
     add = items.append
 
+    # ---- LDS-DMA of K(t+4) and V(t+3): early in the step (longest flight before the vmcnt of the next step's end)
+    for n, (kind, i, slot) in enumerate([("K", i, slot_kd) for i in range(4)] + [("V", i, slot_vd) for i in range(4)]):
+        add(Item(f"dma{kind}{i}", dma_lines(kind, i, slot), DMA_COST, earliest=1 + DMA_EVERY * n, deadline=1 + DMA_EVERY * n + 6))
     # ---- softmax finish of tile t: element e -> (kk, qi, w): register sc[qi][kk>>1][8(kk&1) + w]
     exp_items = {}
     for kk in range(4):
@@ -394,17 +398,15 @@ def build_step(E, phase, prescale, cold):
                     lo = sreg(cur, qi, kk >> 1, 8 * (kk & 1) + w - 1)
                     add(Item(f"pack{kk}{qi}{w >> 1}", [f"v_cvt_pk_bf16_f32 {vr(preg(qi, kk, w >> 1))}, {vr(lo)}, {vr(r)}"], 4,
                              deadline=dl_pack, deps=[(ex, 1), (exp_items[(kk, qi, w - 1)], 1)]))
-    # ---- V^T fragment reads of tile t (window of NVW fragments)
+    # ---- V^T fragment reads of tile t (window of NVW fragments); one counted wait per k-step group of 4 fragments
     for f in range(16):
+        kk = f >> 2
         earliest = 0 if f < NVW else 32 + 2 * (f - NVW) + 2
-        add(Item(f"vrd{f}", vrd_lines(f, slot_v, f % NVW), 2, earliest=earliest, deadline=32 + 2 * f - 3, lds=2))
+        add(Item(f"vrd{f}", vrd_lines(f, slot_v, f % NVW), 2, earliest=earliest, deadline=max(earliest, 32 + 8 * kk - 4), lds=2))
     # ---- K fragment reads of tile t+2 into the AGPRs that tile t+1's phase A has finished with
     for i in range(16):
         sub, ks = i >> 3, i & 7
         add(Item(f"krd{i}", [krd_line(sub, ks, slot_k2)], 2, earliest=2 * i + 3, deadline=58, lds=1))
-    # ---- LDS-DMA of K(t+4) and V(t+3): one piece every few gaps from the start of the step
-    for n, (kind, i, slot) in enumerate([("K", i, slot_kd) for i in range(4)] + [("V", i, slot_vd) for i in range(4)]):
-        add(Item(f"dma{kind}{i}", dma_lines(kind, i, slot) + [dma_advance(kind, i)], 18, earliest=1 + 3 * n, deadline=40))
     # ---- row max of tile t+1 (phase B: its scores are complete, and a ragged tile has been masked, by then)
     for qi in range(2):
         c0 = max_chain_lines(nxt, qi, 0)
@@ -418,14 +420,15 @@ def build_step(E, phase, prescale, cold):
     gaps, load = schedule(items, 64)
 
     # ---- emission, with lgkmcnt tracking (LDS results return in order)
-    lds_issued = 0
+    lds_issued = 0                # LDS results requested so far in this step (the step starts with none outstanding)
+    lds_done = 0                  # ... of which this many are known complete (by the last counted wait)
     vrd_done_at = {}              # fragment -> value of lds_issued right after its second read
     lab_mask, lab_mask_ret = E.label("mask"), E.label("maskret")
     lab_resc, lab_resc_ret = E.label("rescale"), E.label("rescret")
     lab_skip = E.label("nodecide")
     first_c = [vr(negm(qi), 16) if prescale else "0" for qi in range(2)]
     for g in range(64):
-        if g == 32:
+        if g == 32 and flagged:
             # between the phases: tile t+1 ragged? (scalar flag computed at the start of the step)
             E.e(f"s_cmp_eq_u32 {sr(S['NEXT'])}, 2")
             E.e(f"s_cbranch_scc1 {lab_mask}")
@@ -437,9 +440,10 @@ def build_step(E, phase, prescale, cold):
             p = g - 32
             kk, db, qi = p >> 3, (p >> 1) & 3, p & 1
             f = kk * 4 + db
-            if qi == 0:
-                outstanding_after = lds_issued - vrd_done_at[f]
-                E.e(f"s_waitcnt lgkmcnt({min(outstanding_after, 15)})")
+            need = max(vrd_done_at[ff] for ff in range(4 * kk, 4 * kk + 4)) if (db == 0 and qi == 0) else vrd_done_at[f]
+            if need > lds_done:
+                E.e(f"s_waitcnt lgkmcnt({min(lds_issued - need, 15)})")
+                lds_done = max(need, lds_issued - 15) if lds_issued - need > 15 else need
             E.e(mfma_pv(qi, db, kk, f % NVW))
         for it in gaps[g]:
             for ln in it.lines:
@@ -447,27 +451,27 @@ def build_step(E, phase, prescale, cold):
             lds_issued += it.lds
             if it.name.startswith("vrd"):
                 vrd_done_at[int(it.name[3:])] = lds_issued
-    # ---- end of step: rescale decision (skipped when there is no next tile), waits, barrier
-    E.e(f"s_cmp_eq_u32 {sr(S['NEXT'])}, 0")
-    E.e(f"s_cbranch_scc1 {lab_skip}")
+    # ---- end of step: rescale decision (flagged copy: skipped when there is no next tile), waits, barrier
+    if flagged:
+        E.e(f"s_cmp_eq_u32 {sr(S['NEXT'])}, 0")
+        E.e(f"s_cbranch_scc1 {lab_skip}")
     if prescale:
-        E.e(f"v_cmp_lt_f32 vcc, {THR}, {vr(V_MT + 1)}")
-        E.e(f"s_mov_b64 {sr(S['TMP64'], 2)}, vcc")
-        E.e(f"v_cmp_lt_f32 vcc, {THR}, {vr(V_MT + 3)}")
+        E.e(f"v_max_f32 {vr(V_T0)}, {vr(V_MT + 1)}, {vr(V_MT + 3)}")
     else:
-        for qi in range(2):
-            E.e(f"v_sub_f32 {vr(V_T0)}, {vr(V_MT + 2 * qi + 1)}, {vr(V_M + qi)}")
-            E.e(f"v_mul_f32 {vr(V_T0)}, {sr(S['SCALE'])}, {vr(V_T0)}")
-            E.e(f"v_cmp_lt_f32 vcc, {THR}, {vr(V_T0)}")
-            if qi == 0:
-                E.e(f"s_mov_b64 {sr(S['TMP64'], 2)}, vcc")
-    E.e(f"s_or_b64 {sr(S['TMP64'], 2)}, {sr(S['TMP64'], 2)}, vcc")
-    E.e(f"s_cbranch_scc1 {lab_resc}")
-    E.e(f"{lab_resc_ret}:")
-    E.e(f"{lab_skip}:")
+        E.e(f"v_sub_f32 {vr(V_T0)}, {vr(V_MT + 1)}, {vr(V_M)}")
+        E.e(f"v_sub_f32 {vr(V_MT)}, {vr(V_MT + 3)}, {vr(V_M + 1)}")
+        E.e(f"v_max_f32 {vr(V_T0)}, {vr(V_T0)}, {vr(V_MT)}")
+        E.e(f"v_mul_f32 {vr(V_T0)}, {sr(S['SCALE'])}, {vr(V_T0)}")
+    E.e(f"v_cmp_lt_f32 vcc, {THR}, {vr(V_T0)}")
     E.e("s_waitcnt vmcnt(8) lgkmcnt(0)")
+    E.e(f"s_cbranch_vccnz {lab_resc}")
+    E.e(f"{lab_resc_ret}:")
+    if flagged:
+        E.e(f"{lab_skip}:")
+        E.e("s_waitcnt vmcnt(8) lgkmcnt(0)")
     E.e("s_barrier")
-    cold.append((lab_mask, lambda EE, b=nxt, r=lab_mask_ret: emit_mask_block(EE, b, r)))
+    if flagged:
+        cold.append((lab_mask, lambda EE, b=nxt, r=lab_mask_ret: emit_mask_block(EE, b, r)))
     cold.append((lab_resc, lambda EE, b=nxt, r=lab_resc_ret: emit_rescale_block(EE, b, prescale, r)))
     return load
 
@@ -483,14 +487,18 @@ def emit_next_flags(E):
 
 
 def emit_prologue(E, prescale):
+    if STAMP:
+        E.e(f"s_memtime {sr(SBASE + 46, 2)}")          # whole-workgroup stamp (SBASE+46..47 are otherwise unused)
     emit_inputs(E)
     emit_lane_setup(E)
-    # ring fill: K(tb .. tb+3) -> slots 0..3, V(tb .. tb+2) -> slots 0..2   (28 pieces per wave; K(tb) first)
+    # ring fill: K(tb .. tb+3) -> slots 0..3, V(tb .. tb+2) -> slots 0..2   (28 pieces per wave).  Issue order = need order:
+    # K(tb), V(tb), K(tb+1), K(tb+2) must be visible before the first step; K(tb+3), V(tb+1), V(tb+2) are first read in the
+    # second step and are covered by the first step's end-of-step vmcnt(8) + barrier
     emit_issue_tile(E, "K", 0)
     emit_issue_tile(E, "V", 0)
     emit_issue_tile(E, "K", 1)
-    for slot in (2, 3):
-        emit_issue_tile(E, "K", slot)
+    emit_issue_tile(E, "K", 2)
+    emit_issue_tile(E, "K", 3)
     for slot in (1, 2):
         emit_issue_tile(E, "V", slot)
     # accumulators
@@ -520,8 +528,8 @@ def emit_prologue(E, prescale):
     for g in range(32):
         sub, ks, qi = g >> 4, (g >> 1) & 7, g & 1
         E.e(mfma_qk(0, qi, sub, ks, "0"))
-    # K(tb+1) fragments for phase A of the first step; everything of the ring fill landed and visible
-    E.e("s_waitcnt vmcnt(0)")
+    # K(tb+1) fragments for phase A of the first step; K(tb), V(tb), K(tb+1), K(tb+2) landed and visible (12 pieces still fly)
+    E.e("s_waitcnt vmcnt(12)")
     E.e("s_barrier")
     E.nops(16)                                          # the MFMAs above have read their K fragments
     for i in range(16):
@@ -618,24 +626,101 @@ def emit_epilogue(E, prescale):
     E.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
+STAMP = False       # diagnostic build: every workgroup overwrites the first 16 bytes of its first output row with
+                    # (shader cycles of the tile loop, 100 MHz ticks of the tile loop, steps, 0): tools/attn_ab.py --stamp
+ABLATE = set()      # timing-only experiments (WRONG results), tools/build_attn_variant.sh: dma, barrier, exp, lds, max, valu
+
+
+def ablate_line(ln):
+    """Main-loop line -> replacement under the active ablations (None = drop)."""
+    op = ln.split()[0]
+    if "dma" in ABLATE and (op == "buffer_load_dwordx4" or ln.startswith("s_add_u32 m0")):
+        return None
+    if "barrier" in ABLATE and op == "s_barrier":
+        return None
+    if "vmcnt" in ABLATE and ln.startswith("s_waitcnt vmcnt(8)"):
+        return "s_waitcnt lgkmcnt(0)"
+    if "exp" in ABLATE and op == "v_exp_f32":
+        return None
+    if "lds" in ABLATE and op in ("ds_read_b128", "ds_read_b64_tr_b16"):
+        return None
+    if "max" in ABLATE and op in ("v_max3_f32", "v_max_f32", "v_permlane32_swap_b32"):
+        return None
+    if "valu" in ABLATE and op in ("v_fma_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "v_exp_f32", "v_max3_f32", "v_max_f32"):
+        return None
+    return ln
+
+
 def generate(prescale):
     E = Emitter()
     cold = []
     emit_prologue(E, prescale)
-    loop, done = E.label("loop"), E.label("done_steps")
-    E.e(f"{loop}:")
+    bulk, done = E.label("bulk"), E.label("done_steps")
+    tails = [E.label(f"tail{p}") for p in range(4)]
+    # plain steps while t < t_end - 2 (their next tile exists and is not the ragged one), then the flagged copy for the last two
+    E.e(f"s_sub_u32 {sr(S['TENDM2'])}, {sr(S['TEND'])}, 2")
+    if STAMP:
+        A = S["ARGS"]
+        E.e(f"s_mov_b32 {sr(A + 8)}, {sr(S['T'])}")
+        E.e(f"s_memtime {sr(A, 2)}")
+        E.e(f"s_memrealtime {sr(A + 2, 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+    E.e(f"s_cmp_ge_i32 {sr(S['T'])}, {sr(S['TENDM2'])}")
+    E.e(f"s_cbranch_scc1 {tails[0]}")
+    E.e(f"{bulk}:")
+    loop_start = len(E.lines)
     loads = []
     for phase in range(4):
+        loads.append(build_step(E, phase, prescale, cold, flagged=False))
+        E.e(f"s_add_u32 {sr(S['T'])}, {sr(S['T'])}, 1")
+        E.e(f"s_cmp_ge_i32 {sr(S['T'])}, {sr(S['TENDM2'])}")
+        if phase < 3:
+            E.e(f"s_cbranch_scc1 {tails[phase + 1]}")
+        else:
+            E.e(f"s_cbranch_scc0 {bulk}")
+    for phase in range(4):
+        E.e(f"{tails[phase]}:")
         emit_next_flags(E)
-        loads.append(build_step(E, phase, prescale, cold))
+        build_step(E, phase, prescale, cold, flagged=True)
         E.e(f"s_add_u32 {sr(S['T'])}, {sr(S['T'])}, 1")
         E.e(f"s_cmp_ge_u32 {sr(S['T'])}, {sr(S['TEND'])}")
-        if phase < 3:
-            E.e(f"s_cbranch_scc1 {done}")
-        else:
-            E.e(f"s_cbranch_scc0 {loop}")
+        E.e(f"s_cbranch_scc1 {done}")
+        if phase == 3:
+            E.e(f"s_branch {tails[0]}")
+    if ABLATE:
+        body = [ablate_line(ln) for ln in E.lines[loop_start:]]
+        E.lines[loop_start:] = [ln for ln in body if ln is not None]
     E.e(f"{done}:")
+    if STAMP:
+        A = S["ARGS"]
+        E.e(f"s_memtime {sr(A + 4, 2)}")
+        E.e(f"s_memrealtime {sr(A + 6, 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_sub_u32 {sr(A)}, {sr(A + 4)}, {sr(A)}")
+        E.e(f"s_sub_u32 {sr(A + 2)}, {sr(A + 6)}, {sr(A + 2)}")
+        E.e(f"s_sub_u32 {sr(A + 8)}, {sr(S['TEND'])}, {sr(A + 8)}")
     emit_epilogue(E, prescale)
+    if STAMP:
+        A = S["ARGS"]
+        skip = E.label("nostamp")
+        E.e(f"s_cmp_lg_u32 {sr(S['WAVE'])}, 0")
+        E.e(f"s_cbranch_scc1 {skip}")
+        E.e(f"s_cmp_lg_u32 {sr(S['PIECE'])}, 0")
+        E.e(f"s_cbranch_scc1 {skip}")
+        E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['QROW0'])}, {sr(S['OROW'])}")
+        E.e(f"v_mov_b32 {vr(8)}, {sr(A)}")
+        E.e(f"v_mov_b32 {vr(9)}, {sr(A + 2)}")
+        E.e(f"v_mov_b32 {vr(10)}, {sr(A + 8)}")
+        E.e(f"s_memtime {sr(S['TMP64'], 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_sub_u32 {sr(S['TMP1'])}, {sr(S['TMP64'])}, {sr(SBASE + 46)}")
+        E.e(f"v_mov_b32 {vr(11)}, {sr(S['TMP1'])}")
+        E.e(f"v_mov_b32 {vr(12)}, {sr(S['TMP0'])}")
+        E.e("s_mov_b64 exec, 1")
+        E.e(f"buffer_store_dwordx4 {vr(8, 4)}, {vr(12)}, {sr(S['OD'], 4)}, 0 offen")
+        E.e("s_waitcnt vmcnt(0)")
+        E.e("s_mov_b64 exec, -1")
+        E.e(f"{skip}:")
     end = E.label("end")
     E.e(f"s_branch {end}")
     for lab, fn in cold:
@@ -646,10 +731,19 @@ def generate(prescale):
 
 
 def main():
+    global GAP_BUDGET, DMA_EVERY, STAMP
     ap = argparse.ArgumentParser()
-    ap.add_argument("--prescale", type=int, default=0)
+    ap.add_argument("--prescale", type=int, default=1)
+    ap.add_argument("--ablate", default="", help="comma list of timing-only ablations (wrong results): dma,barrier,vmcnt,exp,lds,max,valu")
+    ap.add_argument("--stamp", action="store_true", help="diagnostic build: cycle / clock stamps of the tile loop into the output (corrupts it)")
+    ap.add_argument("--budget", type=int, default=GAP_BUDGET)
+    ap.add_argument("--dma-every", type=int, default=DMA_EVERY)
     ap.add_argument("--report", action="store_true", help="print the per-gap issue-cost load of the four steps to stderr")
     a = ap.parse_args()
+    GAP_BUDGET = a.budget
+    DMA_EVERY = a.dma_every
+    STAMP = a.stamp
+    ABLATE.update(x for x in a.ablate.split(",") if x)
     E, loads = generate(bool(a.prescale))
     if a.report:
         for p, ld in enumerate(loads):

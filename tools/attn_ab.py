@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--iters", type=int, default=3, help="launches per library per round")
     ap.add_argument("--check-rows", type=int, default=192)
+    ap.add_argument("--stamp", default="", help="comma list of libraries built with gen_attn_w4.py --stamp: decode their cycle stamps")
     ap.add_argument("--spike", action="store_true", help="also check an input that forces the deferred-rescale branch")
     a = ap.parse_args()
     dev = "cuda"
@@ -90,6 +91,23 @@ def main():
             ok = err <= 2 * err_ref + 2e-2 and bool(torch.isfinite(out.float()).all())
             print(f"check[{cname}] {name}: max|out - ref_f32| = {err:.5f} (bf16 rounding of ref: {err_ref:.5f}), mean {mean:.6f}  "
                   f"{'OK' if ok else 'FAIL'}", flush=True)
+    for name, lib in libs:
+        if name not in a.stamp.split(","):
+            continue
+        out = torch.zeros((1, a.nq, c), dtype=torch.bfloat16, device=dev)
+        fn = runner(lib, q, k, v, a.heads, out)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        raw = out[0, 0::256, :].contiguous().view(torch.int32).view(-1, a.heads, 64)[:, :, :4].reshape(-1, 4).cpu()
+        raw = raw[raw[:, 2] > 0]
+        cyc, ticks, steps = raw[:, 0].double(), raw[:, 1].double(), raw[:, 2].double()
+        per_step = (cyc / steps).median().item()
+        clock = (cyc / ticks * 100).median().item()
+        outside = (raw[:, 3].double() - cyc).median().item()
+        print(f"stamp {name}: {len(raw)} workgroups, median {per_step:.0f} shader cycles per step (64 MFMAs = 2048), "
+              f"in-kernel clock {clock:.0f} MHz, steps {int(steps.median().item())}, prologue+epilogue {outside:.0f} cycles "
+              f"(loop total {cyc.median().item():.0f})", flush=True)
     out = torch.empty((1, a.nq, c), dtype=torch.bfloat16, device=dev)
     fns = [(n, runner(lib, q, k, v, a.heads, out)) for n, lib in libs]
     for _, fn in fns:
