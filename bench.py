@@ -36,10 +36,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
-# HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r01d_attn_pmc_hbm.json:
+# HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r02_attn_w4_pmc.json:
 # separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, gfx950 x2 correction on FETCH_SIZE), keyed by (Nq, Nkv, H).
 # PMC collection cannot run inside the timed bench; other shapes report null.
-PMC_HBM_BYTES_PER_LAUNCH = {(27280, 27280, 24): 2.089e9}
+PMC_HBM_BYTES_PER_LAUNCH = {(27280, 27280, 24): 2.110e9}
 
 
 def seeded(shape, seed, dtype=torch.bfloat16):
@@ -150,7 +150,7 @@ class KernelTimer:
         x_t = sum(s.elapsed_time(e) for nq, nkv, h, s, e in self.attn if nkv <= 1024) * 1e-3
         x_f = sum(4.0 * nq * nkv * h * 128 for nq, nkv, h, s, e in self.attn if nkv <= 1024)
         if x_t > 0:
-            out.append({"kernel": "attn_fwd_kernel<short-KV> (cross-attention, 512 keys)", "bound": "mfma",
+            out.append({"kernel": "attn_fwd_kernel<8,1,short-KV> (cross-attention, 512 keys)", "bound": "mfma",
                         "achieved": round(x_f / x_t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(x_f / x_t / 1e12 / PEAK_BF16_TFLOPS, 4), "total_s": round(x_t, 3)})
         for variant, name in ((256, "conv3d_cl_256_kernel (VAE38 decode, 256x256x64 LDS-DMA tile)"),
@@ -372,7 +372,7 @@ def main():
         st = timer.self_attention_stats()
         roofline = None
         if st:
-            roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel (fg_attn_fwd_bf16, self-attention launches)",
+            roofline = {"bound": "mfma", "kernel": "attn_fwd_w4_kernel (fg_attn_fwd_bf16, self-attention launches: main kernel + split-KV merge)",
                         "achieved": round(st["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(st["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": st["traffic"],
                         "launches": st["launches"], "avg_launch_ms": round(st["avg_s"] * 1e3, 3),

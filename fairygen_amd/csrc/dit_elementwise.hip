@@ -182,6 +182,15 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restric
     const float ms = wave_sum(q) / (float)C;
     const float rinv = 1.0f / sqrtf(ms + eps);
     const int half = head_dim >> 1;
+    // fp32 table: a lane's vectors are 512 channels apart, so when head_dim divides 512 (128 here) every vector of the lane
+    // sits at the same channel offset inside its head and needs the SAME four (cos, sin) pairs: loaded once per row
+    const bool hoist = F32TAB && ctv != nullptr && (512 % head_dim) == 0;
+    f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+    if (hoist) {
+        const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (((lane * 8) % head_dim) >> 1)) * 2);
+        h0 = tp[0];
+        h1 = tp[1];
+    }
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
         const int vi = lane + i * 64;
@@ -193,8 +202,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restric
             if (ctv != nullptr) {
                 const int d0 = (vi * 8) % head_dim;          // channel within the head, multiple of 8
                 if (F32TAB) {
-                    const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (d0 >> 1)) * 2);
-                    const f32x4 t0 = tp[0], t1 = tp[1];      // (c0,s0,c1,s1) (c2,s2,c3,s3)
+                    f32x4 t0 = h0, t1 = h1;                  // (c0,s0,c1,s1) (c2,s2,c3,s3)
+                    if (!hoist) {
+                        const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (d0 >> 1)) * 2);
+                        t0 = tp[0];
+                        t1 = tp[1];
+                    }
                     const float cs[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
