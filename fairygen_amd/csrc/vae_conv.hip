@@ -226,17 +226,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(ConvParams p) {
 // out-of-range lanes (zero padding) write zeros (probed: tools/probes/lds_dma_oob.hip).  2 stages x 64 KiB of dynamic
 // LDS, one `vmcnt(0)` + barrier per step (the simple glds structure of cdna_hip_programming.md §5).
 constexpr int kT2 = 256;                       // tile rows (couts and pixels)
+constexpr int kConv256Default = 25681;         // form of the 256x256 kernel launched by default (see fg_conv3d_cl_bf16)
 constexpr int kTile2 = kT2 * kBK * 2;          // 32 KiB per operand tile
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-__global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
+// WAVES = 8: 2 x 4 waves of 128 couts x 64 pixels (two waves per SIMD).  WAVES = 4: 2 x 2 waves of 128 x 128, one wave per
+// SIMD with the 512-entry register file (256 accumulator registers): every fragment read from LDS feeds 4 MFMAs instead
+// of 2 or 4, and the fragments of the next k-step are read while the current one's MFMAs run (PIPE), across the barrier.
+template <int WAVES, bool PIPE>
+__device__ __forceinline__ void conv3d_cl_256_body(const ConvParams& p) {
+    constexpr int NI = WAVES == 8 ? 2 : 4;          // 32-pixel sub-tiles per wave
+    constexpr int NP = 32 / WAVES;                  // 1-KiB LDS-DMA pieces per wave per operand tile
     extern __shared__ __attribute__((aligned(16))) char smem2[];      // A0 A1 B0 B1, 32 KiB each
     char* const a_lds = smem2;
     char* const b_lds = smem2 + 2 * kTile2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = WAVES == 8 ? wave >> 2 : wave >> 1, wn = WAVES == 8 ? (wave & 3) : (wave & 1);
 
     const int n_ctiles = p.cout_pad / kT2;
     const int ctile = blockIdx.x % n_ctiles;
@@ -250,12 +257,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
 
     // ---- LDS-DMA roles: wave w, instruction i (0..3) fills tile rows 8*(4w+i) .. +7; lane -> (row_local = lane>>3,
     // destination chunk c' = lane&7), source chunk = c' ^ swizzle(row)
-    int pt[4], py[4], px[4], src_chunk[4];
-    bool pv[4];
-    uint32_t w_off[4];
+    int pt[NP], py[NP], px[NP], src_chunk[NP];
+    bool pv[NP];
+    uint32_t w_off[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (4 * wave + i) + (lane >> 3);
+    for (int i = 0; i < NP; ++i) {
+        const int row = 8 * (NP * wave + i) + (lane >> 3);
         src_chunk[i] = (lane & 7) ^ ((row >> 1) & 7);
         const int64_t m = m0 + row;
         pv[i] = m < p.M;
@@ -274,10 +281,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
 
     int ld_dt = 0, ld_dy = 0, ld_dx = 0, ld_cs = 0;
     uint32_t ld_wbase = 0;
-    uint32_t x_off[4];
+    uint32_t x_off[NP];
     auto tap_offsets = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             int yy = py[i] * sstride + ld_dy - pad, xx = px[i] * sstride + ld_dx - pad;
             const bool ok = pv[i] && yy >= 0 && yy < p.H * sstride && xx >= 0 && xx < p.W * sstride;
             if (p.upsample) { yy >>= 1; xx >>= 1; }
@@ -288,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
     auto issue_dma = [&](int buf) {
         const uint32_t cs_bytes = (uint32_t)ld_cs * (kBK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int dst = buf * kTile2 + 8 * (4 * wave + i) * 128;      // wave-uniform LDS byte offset of the 1 KiB piece
+        for (int i = 0; i < NP; ++i) {
+            const int dst = buf * kTile2 + 8 * (NP * wave + i) * 128;      // wave-uniform LDS byte offset of the 1 KiB piece
             const bool cin_ok = ld_cs * kBK + src_chunk[i] * 8 < p.Cin;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t*)(a_lds + dst), 16, w_off[i], ld_wbase + cs_bytes, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void_t*)(b_lds + dst), 16, cin_ok ? x_off[i] : kOOB, cs_bytes, 0, 0);
@@ -307,20 +314,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
         }
     };
 
-    int a_rd[4][4], b_rd[2][4];
+    // (row >> 1) & 7 of the swizzle depends on r only (sub-tile bases are multiples of 32 rows): one base per k-step
+    int a_rd[4], b_rd[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a_rd[i][ks] = lds_off(wm * 128 + i * 32 + r, 2 * ks + hh);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) b_rd[i][ks] = lds_off(wn * 64 + i * 32 + r, 2 * ks + hh);
+        a_rd[ks] = lds_off(wm * 128 + r, 2 * ks + hh);
+        b_rd[ks] = lds_off(wn * (32 * NI) + r, 2 * ks + hh);
     }
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NI];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NI; ++b)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
@@ -329,36 +335,66 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
-        if (step + 1 < nsteps) {      // wave-uniform
-            advance();
-            issue_dma(cur ^ 1);
+    auto read_frags = [&](bf16x8 (&af)[4], bf16x8 (&bfg)[NI], int buf, int ks) {
+        const char* ab = a_lds + buf * kTile2;
+        const char* bb = b_lds + buf * kTile2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + a_rd[ks] + i * 4096);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bfg[i] = *reinterpret_cast<const bf16x8*>(bb + b_rd[ks] + i * 4096);
+    };
+    auto mfma_block = [&](const bf16x8 (&af)[4], const bf16x8 (&bfg)[NI]) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfg[ni], acc[mi][ni], 0, 0, 0);
+    };
+    if constexpr (!PIPE) {
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < nsteps) {      // wave-uniform
+                advance();
+                issue_dma(cur ^ 1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[4], bfg[NI];
+                read_frags(af, bfg, cur, ks);
+                mfma_block(af, bfg);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
+            __syncthreads();
         }
-        const char* ab = a_lds + cur * kTile2;
-        const char* bb = b_lds + cur * kTile2;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[4], bfg[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + a_rd[i][ks]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) bfg[i] = *reinterpret_cast<const bf16x8*>(bb + b_rd[i][ks]);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfg[ni], acc[mi][ni], 0, 0, 0);
+    } else {
+        // software pipeline over k-steps: fragments of k-step s+1 are in flight while the MFMAs of k-step s run; the last
+        // k-step of a stage is multiplied AFTER the barrier, beside the first fragment reads of the next stage
+        bf16x8 afA[4], bfA[NI], afB[4], bfB[NI];
+        read_frags(afA, bfA, 0, 0);
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < nsteps) {
+                advance();
+                issue_dma(cur ^ 1);
+            }
+            read_frags(afB, bfB, cur, 1);
+            mfma_block(afA, bfA);
+            read_frags(afA, bfA, cur, 2);
+            mfma_block(afB, bfB);
+            read_frags(afB, bfB, cur, 3);
+            mfma_block(afA, bfA);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (step + 1 < nsteps) read_frags(afA, bfA, cur ^ 1, 0);
+            mfma_block(afB, bfB);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
-        __syncthreads();
     }
 
     // ---- epilogue (same fragment map as the 128x128 kernel)
     const int cout2 = p.interleave ? p.Cout / 2 : p.Cout;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int64_t m = m0 + wn * 64 + ni * 32 + r;
+    for (int ni = 0; ni < NI; ++ni) {
+        const int64_t m = m0 + wn * (32 * NI) + ni * 32 + r;
         if (m >= p.M) continue;
         int64_t opix = m, frame_stride = 0;
         if (p.interleave) {
@@ -392,6 +428,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) {
             }
     }
 }
+
+__global__ __launch_bounds__(512, 2) void conv3d_cl_256_kernel(ConvParams p) { conv3d_cl_256_body<8, false>(p); }
+__global__ __launch_bounds__(512, 2) void conv3d_cl_256p_kernel(ConvParams p) { conv3d_cl_256_body<8, true>(p); }
+__global__ __launch_bounds__(256, 1) void conv3d_cl_256w4_kernel(ConvParams p) { conv3d_cl_256_body<4, false>(p); }
+__global__ __launch_bounds__(256, 1) void conv3d_cl_256w4p_kernel(ConvParams p) { conv3d_cl_256_body<4, true>(p); }
 
 __global__ void pack_weight_kernel(const bf16* __restrict__ w, bf16* __restrict__ packed, int Cout, int Cin, int ntaps,
                                    int cout_pad, int cin_pad) {
@@ -438,7 +479,7 @@ int fg_conv_tile_choice(int T, int H, int W, int Cout) {
     const int64_t M = (int64_t)T * H * W;
     const int64_t blocks256 = ((M + kT2 - 1) / kT2) * (roundup(Cout, kBMc) / kT2);
     const int variant = conv_variant_override() ? conv_variant_override() : (blocks256 >= 224 ? 256 : 128);
-    return variant == 256 ? 256 : 128;
+    return variant >= 256 ? 256 : 128;
 }
 
 int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, const void* residual, void* out, int T, int H,
@@ -470,11 +511,23 @@ int fg_conv3d_cl_bf16(const void* x, const void* w_packed, const void* bias, con
     p.x_bytes = (uint32_t)x_bytes; p.w_bytes = (uint32_t)w_bytes;
     const int64_t blocks256 = ((p.M + kT2 - 1) / kT2) * (p.cout_pad / kT2);
     if (fg_conv_tile_choice(T, H, W, Cout) == 256) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cl_256_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile2);
-        FG_CHECK_ARG(attr == hipSuccess, "fg_conv3d_cl_bf16: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
         FG_CHECK_ARG(blocks256 < (1ll << 31), "fg_conv3d_cl_bf16: grid too large");
-        hipLaunchKernelGGL(conv3d_cl_256_kernel, dim3((unsigned)blocks256), dim3(512), 4 * kTile2, (hipStream_t)stream, p);
+        // FAIRYGEN_CONV_TILE: 256 = default form (8 waves, fragments of the next k-step read beside the MFMAs of the current one and across the
+        // barrier: +7-10 % on the main shapes); 2568 / 25681 / 2564 / 25641 force <8 waves> / <8, pipelined> / <4 waves> / <4, pipelined>
+        // (the compiler-scheduled 4-wave forms measure 8-14 % SLOWER than the 8-wave ones: tools/conv_ab.sh)
+        const int form = conv_variant_override() > 256 ? conv_variant_override() : kConv256Default;
+#define FG_LAUNCH_256(KERNEL, W)                                                                                                 \
+    do {                                                                                                                         \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),                                \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kTile2);              \
+        FG_CHECK_ARG(attr == hipSuccess, "fg_conv3d_cl_bf16: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));       \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)blocks256), dim3(W * 64), 4 * kTile2, (hipStream_t)stream, p);                 \
+    } while (0)
+        if (form == 2564) FG_LAUNCH_256(conv3d_cl_256w4_kernel, 4);
+        else if (form == 25641) FG_LAUNCH_256(conv3d_cl_256w4p_kernel, 4);
+        else if (form == 25681) FG_LAUNCH_256(conv3d_cl_256p_kernel, 8);
+        else FG_LAUNCH_256(conv3d_cl_256_kernel, 8);
+#undef FG_LAUNCH_256
         return fg_launch_status("fg_conv3d_cl_bf16 (256x256)");
     }
     const int64_t blocks = ((p.M + kBNp - 1) / kBNp) * (p.cout_pad / kBMc);
