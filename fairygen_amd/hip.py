@@ -28,6 +28,7 @@ _SIGNATURES = {
     "fg_copy_groups_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
+    "fg_gemm_bias_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
@@ -260,6 +261,22 @@ def copy_groups(src, src_group_stride, src_ld, dst, dst_group_stride, dst_ld, gr
     _call("fg_copy_groups_bf16", _ptr(src), src_group_stride, src_ld, _ptr(dst), dst_group_stride, dst_ld, groups, rows,
           cols, _stream(src))
     return dst
+
+
+def gemm_bias(x, weight, bias, out=None):
+    """x (..., K) with dense last dim (rows may be strided: 2-D view with stride(0) = lda) @ weight (N, K)^T + bias -> (..., N)."""
+    _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
+    k = x.shape[-1]
+    n = weight.shape[0]
+    if weight.shape != (n, k) or not weight.is_contiguous() or bias.shape != (n,) or x.stride(-1) != 1:
+        raise HipLibraryError("gemm_bias: weight must be a contiguous (N, K) tensor, bias (N,), x dense in its last dim")
+    x2 = x.reshape(-1, k) if x.is_contiguous() else (x.squeeze(0) if x.dim() == 3 else x)
+    if x2.dim() != 2:
+        raise HipLibraryError("gemm_bias: strided input must be 2-D (rows, K) or (1, rows, K)")
+    m, lda = x2.shape[0], x2.stride(0)
+    out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
+    _call("fg_gemm_bias_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 0, _stream(x))
+    return out
 
 
 FP8_E4M3FN_MAX = 448.0

@@ -70,6 +70,13 @@ int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_
                         int64_t rows, int C, float eps,
                         int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream);
 
+/* nn.Linear of the DiT blocks (models/wan_video_dit.py:130-133,156-159,208-209): c[M,N] = a[M,K] w[N,K]^T + bias[N], bf16 in and
+ * out, fp32 accumulation, bias added to the accumulator before the one bf16 rounding (as the library GEMM does).  a has leading
+ * dimension lda, c ldc (elements); w is the row-major (out_features, in_features) weight; N %% 256 == 0, K %% 64 == 0.
+ * flags: reserved (0).  Hand-scheduled 256x256x64 MFMA kernel (csrc/gen_gemm_w4.py). */
+int fg_gemm_bias_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, int flags, fg_stream_t stream);
+
 /* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
  * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,
  * CrossAttention.forward :176-177 with cos==sin==NULL).  x has leading dimension ldx (so q/k slices of a
