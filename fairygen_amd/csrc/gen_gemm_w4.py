@@ -94,11 +94,12 @@ def emit_lane_setup(E):
     E.nops(2)
 
 
-def dma_piece(op, i, stage):
+def dma_piece(op, i, stage, koff=None):
     base, dst, rs = (V_DW, S["WDST"], S["WD"]) if op == "W" else (V_DX, S["XDST"], S["XD"])
+    koff = S["KOFF"] if koff is None else koff
     return [f"s_add_u32 m0, {sr(dst)}, {stage * STAGE + i * 1024}",
             "s_nop 0",
-            f"buffer_load_dwordx4 {vr(base + i)}, {sr(rs, 4)}, {sr(S['KOFF'])} offen lds"]
+            f"buffer_load_dwordx4 {vr(base + i)}, {sr(rs, 4)}, {sr(koff)} offen lds"]
 
 
 def frag_read(op, blk, fset, stage, ks):
@@ -113,7 +114,7 @@ def mfma(ni, mi, fset):
     return f"v_mfma_f32_32x32x16_bf16 {d}, {vr(fset + 4 * ni, 4)}, {vr(fset + 16 + 4 * mi, 4)}, {d}"
 
 
-def build_iteration(E, stage, first, budget):
+def build_iteration(E, stage, first, budget, koff_w=None, koff_x=None, advance=True):
     """One K-step of 64 (tile t in LDS stage `stage`): block 0 = last k-step of tile t-1 (fragment set F1, read before the
     barrier), blocks 1..3 = k-steps 0..2 of tile t; reads of k-step s+1 beside the MFMAs of k-step s; the LDS-DMA of tile t+1
     goes to the other stage.  first: the peeled first iteration (no block 0)."""
@@ -134,7 +135,7 @@ def build_iteration(E, stage, first, budget):
                 add(Item(f"rd{ks}{op}{blk}", [frag_read(op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest),
                          lds=1))
     for n, (op, i) in enumerate([("W", i) for i in range(8)] + [("X", i) for i in range(8)]):
-        add(Item(f"dma{op}{i}", dma_piece(op, i, stage ^ 1), 12, earliest=1 + 2 * n, deadline=1 + 2 * n + 8))
+        add(Item(f"dma{op}{i}", dma_piece(op, i, stage ^ 1, koff_w if op == "W" else koff_x), 12, earliest=1 + 2 * n, deadline=1 + 2 * n + 8))
     gaps, load = schedule(items, 64, budget)
     lds_issued, lds_done, done_at = 0, 0, {}
     # reads of R(t-1,3) (set F1, block 0) completed before the barrier (lgkmcnt(0))
@@ -156,7 +157,8 @@ def build_iteration(E, stage, first, budget):
             lds_issued += it.lds
             if it.lds:
                 done_at[it.name] = lds_issued
-    E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
+    if advance:
+        E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
     E.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E.e("s_barrier")
     return load
