@@ -263,7 +263,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stamp", action="store_true")
     ap.add_argument("--budget", type=int, default=18)
+    ap.add_argument("--dma-every-x2", type=int, default=G.DMA_EVERY_X2)
     a = ap.parse_args()
+    G.DMA_EVERY_X2 = a.dma_every_x2
     E, load = generate(a.stamp, a.budget)
     out = ["// GENERATED by gen_conv_w4.py : do not edit", "#define FG_CONV_W4_ASM \\"]
     for ln in E.lines:

@@ -18,6 +18,7 @@ import sys
 
 from gen_attn_w4 import Emitter, Item, schedule, vr, ar, sr
 
+DMA_EVERY_X2 = 4                    # LDS-DMA pieces are issued every DMA_EVERY_X2 / 2 MFMA gaps from the start of a K-step
 STAGE, XOFF = 65536, 32768          # LDS: stage s at s*64 KiB: W tile (32 KiB) then X tile (32 KiB)
 SB = 40
 S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, WAVE=16, NK=17, LDA=18, LDC=19, KOFF=20, KB=21, T=22, TMP0=23, TMP1=24,
@@ -135,7 +136,8 @@ def build_iteration(E, stage, first, budget, koff_w=None, koff_x=None, advance=T
                 add(Item(f"rd{ks}{op}{blk}", [frag_read(op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest),
                          lds=1))
     for n, (op, i) in enumerate([("W", i) for i in range(8)] + [("X", i) for i in range(8)]):
-        add(Item(f"dma{op}{i}", dma_piece(op, i, stage ^ 1, koff_w if op == "W" else koff_x), 12, earliest=1 + 2 * n, deadline=1 + 2 * n + 8))
+        g0 = 1 + (n * DMA_EVERY_X2) // 2
+        add(Item(f"dma{op}{i}", dma_piece(op, i, stage ^ 1, koff_w if op == "W" else koff_x), 12, earliest=g0, deadline=g0 + 8))
     gaps, load = schedule(items, 64, budget)
     lds_issued, lds_done, done_at = 0, 0, {}
     # reads of R(t-1,3) (set F1, block 0) completed before the barrier (lgkmcnt(0))
