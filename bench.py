@@ -153,7 +153,7 @@ class KernelTimer:
             out.append({"kernel": "attn_fwd_kernel<8,1,short-KV> (cross-attention, 512 keys)", "bound": "mfma",
                         "achieved": round(x_f / x_t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(x_f / x_t / 1e12 / PEAK_BF16_TFLOPS, 4), "total_s": round(x_t, 3)})
-        for variant, name in ((256, "conv3d_cl_256_kernel (VAE38 decode, 256x256x64 LDS-DMA tile)"),
+        for variant, name in ((256, "conv3d_cl_w4_kernel / conv3d_cl_256p_kernel (VAE38 decode, 256x256x64 LDS-DMA tile; hand-scheduled 4-wave form where Cin % 64 == 0)"),
                               (128, "conv3d_cl_kernel (VAE38 decode, 128x128x64 tile: low-resolution / odd-channel layers)")):
             rec = [(f, b, s.elapsed_time(e) * 1e-3) for v, f, b, s, e in self.conv if v == variant]
             if rec:

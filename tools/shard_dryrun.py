@@ -20,6 +20,7 @@ from fairygen_amd import sequence_parallel as sp  # noqa: E402
 class DryShard(sp.TokenShard):
     def __init__(self, world_size, rank, attn_mode):
         self.group, self.attn_mode, self.world_size, self.rank = None, attn_mode, world_size, rank
+        self.active = world_size > 1
 
     def _gather_rows(self, local, size):
         # every "peer" contributes a copy of the local rows: same statistics as real data (all-zero peers would let the
