@@ -246,7 +246,7 @@ class WanVideoUnit_CfgMerger(PipelineUnit):
         self.concat_tensor_names = ["context"]
 
     def process(self, pipe, inputs_shared, inputs_posi, inputs_nega):
-        if not inputs_shared["cfg_merge"]:
+        if not inputs_shared.get("cfg_merge"):
             return inputs_shared, inputs_posi, inputs_nega
         for name in self.concat_tensor_names:
             tensor_posi, tensor_nega, tensor_shared = inputs_posi.get(name), inputs_nega.get(name), inputs_shared.get(name)
