@@ -1,0 +1,539 @@
+#!/usr/bin/env python3
+"""Generator of the PERSISTENT form of the hand-scheduled DiT bias-GEMM (gemm_p_kernel in csrc/dit_gemm.hip):
+C[M,N] = A[M,K] W[N,K]^T + bias (+ epilogue), bf16 in / out, fp32 accumulate.
+
+    python3 gen_gemm_p.py --nb 4|3 [--stamp] > gemm_p{nb}_asm.inc
+
+Same core as gen_gemm_w4.py (4 waves, one per SIMD; 256 activation rows x NB*64 weight rows x 64 k per step; LDS-DMA into 2
+stages; fragments one k-step ahead, across the barrier; every fragment read feeds NB or 4 MFMAs) plus what the data-parallel
+form measured as missing: ONE workgroup per CU walks a list of output tiles (written to LDS by the C++ wrapper:
+XCD-aware, grouped raster), the first k-slice of the next tile is fetched while the epilogue of the current one runs, lane
+constants are set up once, the first k-step of a tile multiplies onto C = 0 (no accumulator clearing), and a 256 x 192 tile
+(--nb 3) is available for the N = 3072 shapes (1712 tiles = 6.7 rounds of 256 CUs instead of 5.02 -> 6).
+Epilogue modes (FLAGS): 0 = bias; 2 = x + gate * bf16(acc + bias) with the residual x read in place and gate per token class
+(GateModule of the DiT block, models/wan_video_dit.py:188-193,225,228); 3 = x + bf16(acc + bias) (cross-attention residual :226).
+"""
+import argparse
+import sys
+
+from gen_attn_w4 import Emitter, Item, schedule, vr, ar, sr
+
+STAGE, XOFF = 65536, 32768
+TAB = 131072                           # tile records (48 B each) above the two stages
+SB = 36                                # s32..s34 are reserved by the compiler (stack / frame / base pointer)
+S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, GD=16, WAVE=20, NK=21, LDA=22, LDC=23, KOFF=24, T=25, TI=26, TMP0=27,
+                                TMP1=28, TMP2=29, WDST=30, XDST=31, KW=32, FLAGS=33, FIRST=34, GLD=35, TMP64=36, ST1=38,
+                                GBASE=40, M0ROW=42, REC=44).items()}      # REC: 16 SGPRs of the current tile record
+NSREG = 60
+F0, F1 = 0, 32
+V_WRD, V_XRD = 64, 72
+V_DW, V_DX = 80, 88
+# lane constants of the epilogue (set up once per kernel)
+V_COLB = 96        # fragment layout (lane = (r, hh): row r of a 32-row block, columns 8g + 4hh + 0..3): column byte offset in the tile
+V_LW = 97          # LDS address this lane writes its fragment-layout words to (+ 64ni + 16g)
+V_LR = 98          # LDS address this lane reads row-major words from: lane i = row i>>4 of a 4-row group, columns 8*(i&15) + 0..7
+V_SOFF = 99        # row-major byte offset in the output tile (out of range for the idle lanes of the 192-column tile)
+V_RROW = 100       # row-major row of the tile, without the 32mi + 4it part
+V_GOFF = 101       # row-major column byte offset (gate table)
+V_TB = 102         # v102..111 temporaries
+V_BIASRAW = 112    # v112..143: the tile's bias words, loaded when the tile starts (they land during the k-loop)
+V_YR = 144         # v144..175: one 32-row block of y read back row-major (8 x 4 words)
+V_XA, V_XB = 176, 208      # residual words of the current / next 32-row block
+V_G0, V_G1 = 240, 244      # the lane's 8 gate values for token class 0 / 1 (loaded when the tile starts)
+V_PW, V_PX, V_PD = 248, 249, 250   # L2 prefetch: byte offset of this lane's row of the wave's W / X tile part (one 128-byte line per
+                                   # lane and k-slice), dummy destination
+V_T = 224          # setup temporaries v224..230
+V_REC = 144        # v144, v146..161: tile record loads (outside the epilogue)
+OOB = 0x80000000
+
+
+class Cfg:
+    lbase = STAGE                        # the epilogue's transpose buffers live in stage 1 (the next tile's first slice goes to stage 0)
+    dma_step = 2.0                       # MFMA gaps between two LDS-DMA pieces (--dma-step)
+    dma_first = 1                        # gap of the first piece
+    pf_dist = 0                          # L2 prefetch distance in k-slices beyond the slice the step's LDS-DMA fetches (0 = off)
+    ablate = ""                          # timing-only builds (wrong results): "nodma" = no LDS-DMA inside the k-loop, "samek", "l1"
+
+    def __init__(self, nb):
+        self.nb = nb                     # 32-row weight blocks per wave
+        self.g16 = nb * 4                # MFMAs per k-step
+        self.gaps = 4 * self.g16         # MFMAs per K-step of 64
+        self.npw = 2 * nb                # weight LDS-DMA pieces per wave per tile
+        self.rs = nb * 64 + 16           # LDS row stride of the transpose buffer (bytes): a 32-row block of the wave's 128 x NB*32 part
+        self.wsz = 32 * self.rs
+
+
+def acc(ni, mi, j=0):
+    return (ni * 4 + mi) * 16 + j
+
+
+def emit_setup(E, C):
+    """%0 kernarg-independent scalars: %0 wave, %1 K/64, %2 lda bytes, %3 ldc bytes, %4 K bytes, %5 flags, %6 first_rows (gate class)."""
+    for n, name in enumerate(["WAVE", "NK", "LDA", "LDC", "KW", "FLAGS", "FIRST"]):
+        E.e(f"s_mov_b32 {sr(S[name])}, %{n}")
+    for base in (S["XD"], S["WD"], S["CD"], S["BD"], S["GD"]):
+        E.e(f"s_mov_b32 {sr(base + 3)}, 0x00020000")
+    E.e(f"s_mul_i32 {sr(S['WDST'])}, {sr(S['WAVE'])}, {C.npw * 1024}")
+    E.e(f"s_lshl_b32 {sr(S['XDST'])}, {sr(S['WAVE'])}, 13")
+    E.e(f"s_add_u32 {sr(S['XDST'])}, {sr(S['XDST'])}, {XOFF}")
+    E.e(f"s_mov_b32 {sr(S['TI'])}, 0")
+    E.e(f"v_mov_b32 {vr(255)}, 0")
+    E.nops(4)
+    L, R, HH, SW, T0, T1, T2 = (V_T + i for i in range(7))
+    E.e(f"v_mbcnt_lo_u32_b32 {vr(L)}, -1, 0")
+    E.e(f"v_mbcnt_hi_u32_b32 {vr(L)}, -1, {vr(L)}")
+    E.e(f"v_and_b32 {vr(R)}, 31, {vr(L)}")
+    E.e(f"v_lshrrev_b32 {vr(HH)}, 5, {vr(L)}")
+    E.e(f"v_bfe_u32 {vr(SW)}, {vr(R)}, 1, 3")
+    E.e(f"v_lshlrev_b32 {vr(T0)}, 7, {vr(R)}")
+    E.e(f"s_lshr_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 1")
+    E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {C.nb * 4096}")          # weight half of this wave
+    E.e(f"s_and_b32 {sr(S['TMP1'])}, {sr(S['WAVE'])}, 1")
+    E.e(f"s_lshl_b32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, 14")
+    E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {XOFF}")
+    for ks in range(4):
+        E.e(f"v_or_b32 {vr(T1)}, {2 * ks}, {vr(HH)}")
+        E.e(f"v_xor_b32 {vr(T1)}, {vr(T1)}, {vr(SW)}")
+        E.e(f"v_lshl_add_u32 {vr(T1)}, {vr(T1)}, 4, {vr(T0)}")
+        E.e(f"v_add_u32 {vr(V_WRD + ks)}, {sr(S['TMP0'])}, {vr(T1)}")
+        E.e(f"v_add_u32 {vr(V_XRD + ks)}, {sr(S['TMP1'])}, {vr(T1)}")
+        E.e(f"v_add_u32 {vr(V_WRD + 4 + ks)}, {STAGE}, {vr(V_WRD + ks)}")
+        E.e(f"v_add_u32 {vr(V_XRD + 4 + ks)}, {STAGE}, {vr(V_XRD + ks)}")
+    # LDS-DMA source offsets (piece i of this wave: tile rows 8*(w*P + i) .. +7)
+    E.e(f"v_lshrrev_b32 {vr(T0)}, 3, {vr(L)}")
+    E.e(f"v_lshrrev_b32 {vr(T1)}, 4, {vr(L)}")
+    E.e(f"v_and_b32 {vr(T2)}, 7, {vr(L)}")
+    for op, npw, base, stride in (("W", C.npw, V_DW, S["KW"]), ("X", 8, V_DX, S["LDA"])):
+        E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, {8 * npw}")
+        for i in range(npw):
+            E.e(f"v_add_u32 {vr(SW)}, {4 * (i & 1)}, {vr(T1)}")
+            E.e(f"v_and_b32 {vr(SW)}, 7, {vr(SW)}")
+            E.e(f"v_xor_b32 {vr(SW)}, {vr(SW)}, {vr(T2)}")
+            E.e(f"v_lshlrev_b32 {vr(SW)}, 4, {vr(SW)}")
+            E.e(f"v_add_u32 {vr(R)}, {8 * i}, {vr(T0)}")
+            E.e(f"v_add_u32 {vr(R)}, {sr(S['TMP0'])}, {vr(R)}")
+            E.e(f"v_mul_lo_u32 {vr(base + i)}, {vr(R)}, {sr(stride)}")
+            E.e(f"v_add_u32 {vr(base + i)}, {vr(base + i)}, {vr(SW)}")
+    # L2 prefetch offsets: lane l <-> row l of this wave's 8*npw weight rows / 64 activation rows
+    E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, {8 * C.npw}")
+    E.e(f"v_add_u32 {vr(V_PW)}, {sr(S['TMP0'])}, {vr(L)}")
+    E.e(f"v_mul_lo_u32 {vr(V_PW)}, {vr(V_PW)}, {sr(S['KW'])}")
+    if 8 * C.npw < 64:
+        E.e(f"v_cmp_le_u32 vcc, {8 * C.npw}, {vr(L)}")
+        E.e(f"v_mov_b32 {vr(T2)}, {OOB}")
+        E.e("s_nop 1")
+        E.e(f"v_cndmask_b32 {vr(V_PW)}, {vr(V_PW)}, {vr(T2)}, vcc")
+    E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 6")
+    E.e(f"v_add_u32 {vr(V_PX)}, {sr(S['TMP0'])}, {vr(L)}")
+    E.e(f"v_mul_lo_u32 {vr(V_PX)}, {vr(V_PX)}, {sr(S['LDA'])}")
+    # epilogue lane constants (see the register map)
+    I4, I15 = T0, T1
+    E.e(f"v_and_b32 {vr(R)}, 31, {vr(L)}")
+    E.e(f"v_lshrrev_b32 {vr(HH)}, 5, {vr(L)}")
+    E.e(f"v_lshrrev_b32 {vr(I4)}, 4, {vr(L)}")
+    E.e(f"v_and_b32 {vr(I15)}, 15, {vr(L)}")
+    E.e(f"s_lshr_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 1")
+    E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {C.nb * 64}")            # column byte offset of the wave's part
+    E.e(f"v_lshlrev_b32 {vr(V_COLB)}, 3, {vr(HH)}")
+    E.e(f"v_add_u32 {vr(V_COLB)}, {sr(S['TMP0'])}, {vr(V_COLB)}")
+    E.e(f"s_mul_i32 {sr(S['TMP1'])}, {sr(S['WAVE'])}, {C.wsz}")
+    E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {C.lbase}")             # this wave's transpose buffer
+    E.e(f"v_mul_u32_u24 {vr(V_LW)}, {C.rs}, {vr(R)}")
+    E.e(f"v_lshl_add_u32 {vr(V_LW)}, {vr(HH)}, 3, {vr(V_LW)}")
+    E.e(f"v_add_u32 {vr(V_LW)}, {sr(S['TMP1'])}, {vr(V_LW)}")
+    E.e(f"v_mul_u32_u24 {vr(V_LR)}, {C.rs}, {vr(I4)}")
+    E.e(f"v_lshl_add_u32 {vr(V_LR)}, {vr(I15)}, 4, {vr(V_LR)}")
+    E.e(f"v_add_u32 {vr(V_LR)}, {sr(S['TMP1'])}, {vr(V_LR)}")
+    E.e(f"s_and_b32 {sr(S['TMP1'])}, {sr(S['WAVE'])}, 1")
+    E.e(f"s_lshl_b32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, 7")
+    E.e(f"v_add_u32 {vr(V_RROW)}, {sr(S['TMP1'])}, {vr(I4)}")
+    E.e(f"v_lshlrev_b32 {vr(V_GOFF)}, 4, {vr(I15)}")
+    E.e(f"v_add_u32 {vr(V_GOFF)}, {sr(S['TMP0'])}, {vr(V_GOFF)}")
+    if C.nb == 3:      # lanes 12..15 of every 16 have no columns: their global accesses go out of range (loads 0, stores dropped)
+        E.e(f"v_cmp_le_u32 vcc, 12, {vr(I15)}")
+        E.e(f"v_mov_b32 {vr(T2)}, {OOB}")
+        E.e("s_nop 1")
+        E.e(f"v_cndmask_b32 {vr(V_GOFF)}, {vr(V_GOFF)}, {vr(T2)}, vcc")
+    E.e(f"v_mul_lo_u32 {vr(V_SOFF)}, {vr(V_RROW)}, {sr(S['LDC'])}")
+    E.e(f"v_add_u32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(V_GOFF)}")
+    if C.nb == 3:
+        E.e(f"v_cndmask_b32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(T2)}, vcc")
+    E.nops(2)
+
+
+ACC_K, ACC_E, ACC_W, T_START, R_START = S["ST1"] + 1, SB + 60, SB + 61, SB + 62, SB + 63     # --stamp only (s96..s99)
+
+
+def emit_stamp(E, acc):
+    """acc += cycles since the previous stamp (s_memtime, low 32 bits)."""
+    E.e(f"s_memtime {sr(S['TMP64'], 2)}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e(f"s_sub_u32 {sr(S['TMP2'])}, {sr(S['TMP64'])}, {sr(S['ST1'])}")
+    E.e(f"s_add_u32 {sr(acc)}, {sr(acc)}, {sr(S['TMP2'])}")
+    E.e(f"s_mov_b32 {sr(S['ST1'])}, {sr(S['TMP64'])}")
+
+
+def emit_load_record(E, part):
+    """Tile record TI (48 B in LDS): part 'A' = x base, w base, x bytes -> XD, WD (and REC for part B); sets SCC = 0 / jumps at the end."""
+    T0 = V_REC
+    if part == "A":
+        E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['TI'])}, 6")
+        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {TAB}")
+        E.e(f"v_mov_b32 {vr(T0)}, {sr(S['TMP0'])}")
+        E.e(f"ds_read_b128 {vr(T0 + 2, 4)}, {vr(T0)}")
+        E.e(f"ds_read_b128 {vr(T0 + 6, 4)}, {vr(T0)} offset:16")
+        E.e(f"ds_read_b128 {vr(T0 + 10, 4)}, {vr(T0)} offset:32")
+        E.e(f"ds_read_b128 {vr(T0 + 14, 4)}, {vr(T0)} offset:48")
+        E.e("s_waitcnt lgkmcnt(0)")
+        for i in range(16):
+            E.e(f"v_readfirstlane_b32 {sr(S['REC'] + i)}, {vr(T0 + 2 + i)}")
+        E.nops(2)
+        # record: x_base(0,1) w_base(2,3) c_base(4,5) bias_base(6,7) x_bytes(8) c_bytes(9) valid(10) m0(11) n0_bytes(12) w_bytes(13)
+        E.e(f"s_mov_b64 {sr(S['XD'], 2)}, {sr(S['REC'], 2)}")
+        E.e(f"s_mov_b32 {sr(S['XD'] + 2)}, {sr(S['REC'] + 8)}")
+        E.e(f"s_mov_b64 {sr(S['WD'], 2)}, {sr(S['REC'] + 2, 2)}")
+        E.e(f"s_mov_b32 {sr(S['WD'] + 2)}, {sr(S['REC'] + 13)}")
+    else:
+        E.e(f"s_mov_b64 {sr(S['CD'], 2)}, {sr(S['REC'] + 4, 2)}")
+        E.e(f"s_mov_b32 {sr(S['CD'] + 2)}, {sr(S['REC'] + 9)}")
+        E.e(f"s_mov_b64 {sr(S['BD'], 2)}, {sr(S['REC'] + 6, 2)}")
+        E.e(f"s_mov_b32 {sr(S['M0ROW'])}, {sr(S['REC'] + 11)}")            # m0 of the tile (token class of a row: m0 + row < FIRST)
+        E.e(f"s_add_u32 {sr(S['GD'])}, {sr(S['GBASE'])}, {sr(S['REC'] + 12)}")     # gate vector at the tile's first column
+        E.e(f"s_addc_u32 {sr(S['GD'] + 1)}, {sr(S['GBASE'] + 1)}, 0")
+
+
+def dma_piece(C, op, i, stage):
+    base, dst, rs = (V_DW, S["WDST"], S["WD"]) if op == "W" else (V_DX, S["XDST"], S["XD"])
+    src = vr(base + i) if C.ablate != "l1" else vr(255)          # l1 (timing only): every lane reads the first 16 bytes of the tile
+    return [f"s_add_u32 m0, {sr(dst)}, {stage * STAGE + i * 1024}",
+            "s_nop 0",
+            f"buffer_load_dwordx4 {src}, {sr(rs, 4)}, {sr(S['KOFF'])} offen lds"]
+
+
+def prefetch(C, op, slices_ahead):
+    """One 128-byte line per lane: the k-slice `slices_ahead` beyond KOFF of this wave's rows, pulled into the XCD's L2 (the data
+    is dropped).  The operand slices an XCD has not touched yet come from the Infinity Cache / HBM with a latency that the one
+    k-step between an LDS-DMA and its barrier does not cover (measured: a k-loop that re-reads L2-resident slices runs 2 155
+    cycles per step, the real one 2 430-2 600); the prefetch gives those misses pf_dist more steps."""
+    base, rs = (V_PW, S["WD"]) if op == "W" else (V_PX, S["XD"])
+    return f"buffer_load_dword {vr(V_PD)}, {vr(base)}, {sr(rs, 4)}, {sr(S['KOFF'])} offen offset:{128 * slices_ahead}"
+
+
+def frag_read(op, blk, fset, stage, ks):
+    dst = fset + (0 if op == "W" else 16) + 4 * blk
+    base = (V_WRD if op == "W" else V_XRD) + 4 * stage + ks
+    return f"ds_read_b128 {vr(dst, 4)}, {vr(base)} offset:{blk * 4096}"
+
+
+def mfma(ni, mi, fset, zero_c=False):
+    d = ar(acc(ni, mi), 16)
+    return f"v_mfma_f32_32x32x16_bf16 {d}, {vr(fset + 4 * ni, 4)}, {vr(fset + 16 + 4 * mi, 4)}, {'0' if zero_c else d}"
+
+
+def build_iteration(E, C, stage, first, budget):
+    """One K-step of 64: block 0 = last k-step of the previous stage (set F1), blocks 1..3 = k-steps 0..2 of this stage."""
+    items = []
+    add = items.append
+    g16 = C.g16
+    sets = [F1, F0, F1, F0]
+    for ks, (fset, busy_blk, need_blk) in enumerate([(F0, None, 1), (F1, 0, 2), (F0, 1, 3), (F1, 2, 4)]):
+        for op, nblk in (("W", C.nb), ("X", 4)):
+            for blk in range(nblk):
+                if busy_blk is None or (first and busy_blk == 0):
+                    earliest = 0
+                else:
+                    earliest = g16 * busy_blk + (4 * blk + 3 if op == "W" else 4 * (C.nb - 1) + blk) + 2
+                need = g16 * need_blk + (4 * blk if op == "W" else blk)
+                deadline = min(need - 4, C.gaps - 4)
+                add(Item(f"rd{ks}{op}{blk}", [frag_read(op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest), lds=1))
+    pieces = [("W", i) for i in range(C.npw)] + [("X", i) for i in range(8)]
+    for n, (op, i) in enumerate(pieces if C.ablate != "nodma" else []):
+        g0 = C.dma_first + int(n * C.dma_step)
+        add(Item(f"dma{op}{i}", dma_piece(C, op, i, stage ^ 1), 12, earliest=g0, deadline=g0 + 8))
+    n_pf = 0
+    if C.pf_dist and C.ablate != "nodma":      # after every LDS-DMA piece in program order: the step's wait is vmcnt(n_pf)
+        last = C.dma_first + int((len(pieces) - 1) * C.dma_step) + 8
+        for n, op in enumerate(("W", "X")):
+            add(Item(f"pf{op}", [prefetch(C, op, C.pf_dist)], 8, earliest=last + 1 + 2 * n, deadline=min(last + 9 + 2 * n, C.gaps - 1)))
+            n_pf += 1
+    gaps, load = schedule(items, C.gaps, budget)
+    lds_issued, lds_done, done_at = 0, 0, {}
+    for g in range(C.gaps):
+        b, idx = g // g16, g % g16
+        ni, mi = idx >> 2, idx & 3
+        if not (first and b == 0):
+            ks = b - 1
+            if b >= 1:
+                need = max(done_at[f"rd{ks}W{ni}"], done_at[f"rd{ks}X{mi}"])
+                if need > lds_done:
+                    E.e(f"s_waitcnt lgkmcnt({min(lds_issued - need, 15)})")
+                    lds_done = need if lds_issued - need <= 15 else lds_issued - 15
+            E.e(mfma(ni, mi, sets[b], zero_c=(first and b == 1)))
+        for it in gaps[g]:
+            for ln in it.lines:
+                E.e(ln)
+            lds_issued += it.lds
+            if it.lds:
+                done_at[it.name] = lds_issued
+    if C.ablate != "samek":                        # samek (timing only): every k-step re-reads the tile's second slice (L2-resident)
+        E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
+    E.e(f"s_waitcnt vmcnt({n_pf}) lgkmcnt(0)")
+    E.e("s_barrier")
+    return load
+
+
+def emit_kloop(E, C, budget):
+    """Tile's k-slice 0 is in stage 0 and visible; KOFF = 128."""
+    loop, done = E.label("kloop"), E.label("kdone")
+    E.e(f"s_mov_b32 {sr(S['T'])}, 1")
+    build_iteration(E, C, 0, True, budget)
+    E.e(f"s_cmp_ge_u32 {sr(S['T'])}, {sr(S['NK'])}")
+    E.e(f"s_cbranch_scc1 {done}")
+    E.e(f"{loop}:")
+    for stage in (1, 0):
+        build_iteration(E, C, stage, False, budget)
+        E.e(f"s_add_u32 {sr(S['T'])}, {sr(S['T'])}, 1")
+        E.e(f"s_cmp_ge_u32 {sr(S['T'])}, {sr(S['NK'])}")
+        E.e(f"s_cbranch_scc1 {done}" if stage == 1 else f"s_cbranch_scc0 {loop}")
+    E.e(f"{done}:")
+    for idx in range(C.g16):
+        E.e(mfma(idx >> 2, idx & 3, F1))
+
+
+def n_dma_k0(C):
+    return C.npw + 8 + 2 * C.pf_dist
+
+
+def emit_dma_k0(E, C):
+    """The tile's first k-slice -> stage 0, and the L2 prefetch of the slices the first pf_dist steps will fetch."""
+    E.e(f"s_mov_b32 {sr(S['KOFF'])}, 0")
+    for op, n in (("W", C.npw), ("X", 8)):
+        for i in range(n):
+            for ln in dma_piece(C, op, i, 0):
+                E.e(ln)
+    for d in range(1, C.pf_dist + 1):
+        for op in ("W", "X"):
+            E.e(prefetch(C, op, d))
+    E.e(f"s_mov_b32 {sr(S['KOFF'])}, 128")
+
+
+def qoff(q):
+    return 64 * (q >> 2) + 16 * (q & 3)
+
+
+N_PREFETCH = lambda C: C.nb * 4 + 2          # noqa: E731  VMEM loads of emit_tile_prefetch
+
+
+def emit_tile_prefetch(E, C):
+    """Issued when a tile starts (BD / GD = the tile's bias / gate slices): the bias words in fragment layout -> V_BIASRAW, the
+    lane's 8 gate values of both token classes in row-major layout -> V_G0 / V_G1 (GLD = 0 makes them equal; without a gate table
+    GD points at the bias and the values are not used).  They land during the k-loop."""
+    for q in range(C.nb * 4):
+        E.e(f"buffer_load_dwordx2 {vr(V_BIASRAW + 2 * q, 2)}, {vr(V_COLB)}, {sr(S['BD'], 4)}, 0 offen offset:{qoff(q)}")
+    E.e(f"buffer_load_dwordx4 {vr(V_G0, 4)}, {vr(V_GOFF)}, {sr(S['GD'], 4)}, 0 offen")
+    E.e(f"buffer_load_dwordx4 {vr(V_G1, 4)}, {vr(V_GOFF)}, {sr(S['GD'], 4)}, {sr(S['GLD'])} offen")
+
+
+def emit_epilogue(E, C, n_dma):
+    """acc + bias -> bf16 (fragment layout) -> LDS -> row-major [-> x + gate * y | x + y] -> C with whole-row 16-byte stores.
+    A lane of the 32x32 accumulator holds 4 consecutive columns of one row, so direct stores are 16-byte pieces of 32 different
+    rows per instruction and the store ISSUE takes 20k cycles per tile (measured); through a per-wave LDS transpose (32-row blocks,
+    row stride +16 B) every global access of the epilogue is a dwordx4 of 4 rows x 256 (192) contiguous bytes.
+    n_dma LDS-DMA loads were issued right before; they are older than every VMEM access here, so the counted waits for residual
+    words retire them too and the plain mode waits for them once at the end.  No wait on stores."""
+    nq = C.nb * 4
+    BIAS, TB, GS = 0, V_TB, V_TB + 6
+    E.nops(8)
+    for q in range(nq):
+        lo, hi = V_BIASRAW + 2 * q, V_BIASRAW + 2 * q + 1
+        E.e(f"v_and_b32 {vr(BIAS + 4 * q + 1)}, 0xffff0000, {vr(lo)}")
+        E.e(f"v_lshlrev_b32 {vr(BIAS + 4 * q)}, 16, {vr(lo)}")
+        E.e(f"v_and_b32 {vr(BIAS + 4 * q + 3)}, 0xffff0000, {vr(hi)}")
+        E.e(f"v_lshlrev_b32 {vr(BIAS + 4 * q + 2)}, 16, {vr(hi)}")
+    E.e(f"s_lshl_b32 {sr(S['TMP2'])}, {sr(S['LDC'])}, 2")                      # 4 rows
+    E.e(f"s_mov_b32 {sr(S['TMP0'])}, 0")                                      # scalar row offset of the stores
+    E.e(f"s_mov_b32 {sr(S['TMP1'])}, 0")                                      # ... of the residual loads
+
+    def write_block(mi):
+        for q in range(nq):
+            ni, g = q >> 2, q & 3
+            for j in range(4):
+                E.e(f"v_accvgpr_read_b32 {vr(TB + j)}, {ar(acc(ni, mi, 4 * g + j))}")
+            E.e("s_nop 0")
+            E.e(f"v_pk_add_f32 {vr(TB, 2)}, {vr(TB, 2)}, {vr(BIAS + 4 * q, 2)}")
+            E.e(f"v_pk_add_f32 {vr(TB + 2, 2)}, {vr(TB + 2, 2)}, {vr(BIAS + 4 * q + 2, 2)}")
+            E.e(f"v_cvt_pk_bf16_f32 {vr(TB + 4)}, {vr(TB)}, {vr(TB + 1)}")
+            E.e(f"v_cvt_pk_bf16_f32 {vr(TB + 5)}, {vr(TB + 2)}, {vr(TB + 3)}")
+            E.e(f"ds_write_b64 {vr(V_LW)}, {vr(TB + 4, 2)} offset:{qoff(q)}")
+
+    def read_block():
+        for it in range(8):
+            E.e(f"ds_read_b128 {vr(V_YR + 4 * it, 4)}, {vr(V_LR)} offset:{it * 4 * C.rs}")
+
+    def load_x(buf):
+        for it in range(8):
+            E.e(f"buffer_load_dwordx4 {vr(buf + 4 * it, 4)}, {vr(V_SOFF)}, {sr(S['CD'], 4)}, {sr(S['TMP1'])} offen")
+            E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {sr(S['TMP2'])}")
+
+    def store(it):
+        E.e(f"buffer_store_dwordx4 {vr(V_YR + 4 * it, 4)}, {vr(V_SOFF)}, {sr(S['CD'], 4)}, {sr(S['TMP0'])} offen")
+        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {sr(S['TMP2'])}")
+
+    plain, resid, done = E.label("epiplain"), E.label("epiresid"), E.label("epidone")
+    E.e(f"s_cmp_lt_u32 {sr(S['FLAGS'])}, 2")
+    E.e(f"s_cbranch_scc1 {plain}")
+    E.e(f"s_cmp_eq_u32 {sr(S['FLAGS'])}, 3")
+    E.e(f"s_cbranch_scc1 {resid}")
+    for gated in (True, False):
+        if not gated:
+            E.e(f"{resid}:")
+        else:      # class threshold of the row-major rows: row (of the tile, without 32mi + 4it) >= FIRST - m0 - 32mi - 4it -> class 1
+            E.e(f"s_sub_i32 {sr(S['T'])}, {sr(S['FIRST'])}, {sr(S['M0ROW'])}")
+        write_block(0)
+        load_x(V_XA)
+        for mi in range(4):
+            xbuf = (V_XA, V_XB)[mi & 1]
+            read_block()
+            if mi < 3:
+                write_block(mi + 1)
+                load_x((V_XA, V_XB)[(mi + 1) & 1])
+            E.e("s_waitcnt lgkmcnt(0)")
+            E.e(f"s_waitcnt vmcnt({(8 if mi >= 1 else 0) + (8 if mi < 3 else 0)})")
+            for it in range(8):
+                if gated:
+                    E.e(f"v_cmp_le_i32 vcc, {sr(S['T'])}, {vr(V_RROW)}")
+                    E.e(f"s_sub_i32 {sr(S['T'])}, {sr(S['T'])}, 4")
+                    E.e("s_nop 0")
+                    for j in range(4):
+                        E.e(f"v_cndmask_b32 {vr(GS + j)}, {vr(V_G0 + j)}, {vr(V_G1 + j)}, vcc")
+                for j in range(4):
+                    yw, xw = V_YR + 4 * it + j, xbuf + 4 * it + j
+                    E.e(f"v_lshlrev_b32 {vr(TB)}, 16, {vr(yw)}")
+                    E.e(f"v_and_b32 {vr(TB + 1)}, 0xffff0000, {vr(yw)}")
+                    if gated:
+                        E.e(f"v_lshlrev_b32 {vr(TB + 2)}, 16, {vr(GS + j)}")
+                        E.e(f"v_and_b32 {vr(TB + 3)}, 0xffff0000, {vr(GS + j)}")
+                        E.e(f"v_pk_mul_f32 {vr(TB, 2)}, {vr(TB, 2)}, {vr(TB + 2, 2)}")
+                        E.e(f"v_cvt_pk_bf16_f32 {vr(TB + 4)}, {vr(TB)}, {vr(TB + 1)}")        # bf16(gate * y)
+                        E.e(f"v_lshlrev_b32 {vr(TB)}, 16, {vr(TB + 4)}")
+                        E.e(f"v_and_b32 {vr(TB + 1)}, 0xffff0000, {vr(TB + 4)}")
+                    E.e(f"v_lshlrev_b32 {vr(TB + 2)}, 16, {vr(xw)}")
+                    E.e(f"v_and_b32 {vr(TB + 3)}, 0xffff0000, {vr(xw)}")
+                    E.e(f"v_pk_add_f32 {vr(TB, 2)}, {vr(TB, 2)}, {vr(TB + 2, 2)}")
+                    E.e(f"v_cvt_pk_bf16_f32 {vr(yw)}, {vr(TB)}, {vr(TB + 1)}")
+                store(it)
+        E.e(f"s_branch {done}")
+    # ---- plain: bias only
+    E.e(f"{plain}:")
+    write_block(0)
+    for mi in range(4):
+        read_block()
+        if mi < 3:
+            write_block(mi + 1)
+        E.e("s_waitcnt lgkmcnt(0)")
+        for it in range(8):
+            store(it)
+    E.e("s_waitcnt vmcnt(32)")                       # the LDS-DMA of the next tile's first k-slice has landed (no stall this late)
+    E.e(f"{done}:")
+
+
+def generate(nb, stamp, budget):
+    C = Cfg(nb)
+    E = Emitter()
+    emit_setup(E, C)
+    # %7 gate base (64-bit: row 0 of the gate vector, column 0), %8 gate row stride in bytes (0: one row), %9 bytes of the gate table
+    E.e(f"s_mov_b64 {sr(S['GBASE'], 2)}, %7")
+    E.e(f"s_mov_b32 {sr(S['GLD'])}, %8")
+    E.e(f"s_mov_b32 {sr(S['GD'] + 2)}, %9")
+    E.e(f"s_mov_b32 {sr(S['BD'] + 2)}, {C.nb * 2 * 32 * 2}")
+    end = E.label("pend")
+    tile_loop = E.label("ptile")
+    nodma = E.label("pnodma")
+    if stamp:
+        for r in (ACC_K, ACC_E, ACC_W):
+            E.e(f"s_mov_b32 {sr(r)}, 0")
+        E.e(f"s_memrealtime {sr(S['TMP64'], 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_mov_b32 {sr(R_START)}, {sr(S['TMP64'])}")
+        E.e(f"s_memtime {sr(S['TMP64'], 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_mov_b32 {sr(T_START)}, {sr(S['TMP64'])}")
+        E.e(f"s_mov_b32 {sr(S['ST1'])}, {sr(S['TMP64'])}")
+    emit_load_record(E, "A")
+    E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
+    E.e(f"s_cbranch_scc1 {end}")
+    emit_dma_k0(E, C)
+    emit_load_record(E, "B")
+    emit_tile_prefetch(E, C)
+    E.e(f"s_waitcnt vmcnt({N_PREFETCH(C)})")        # the k-slice (and the L2 prefetches behind it) has landed; the bias / gate words may still be on their way
+    E.e("s_barrier")
+    E.e(f"{tile_loop}:")
+    if stamp:
+        emit_stamp(E, ACC_W)
+    emit_kloop(E, C, budget)
+    if stamp:
+        emit_stamp(E, ACC_K)
+    # next tile: its record (part A: operand descriptors) and the LDS-DMA of its first k-slice go out BEFORE the epilogue of the
+    # current tile, whose output / bias / gate descriptors (part B) stay those of the current tile until the epilogue is through
+    E.e(f"s_add_u32 {sr(S['TI'])}, {sr(S['TI'])}, 1")
+    emit_load_record(E, "A")
+    E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
+    E.e(f"s_cbranch_scc1 {nodma}")
+    emit_dma_k0(E, C)
+    E.e(f"{nodma}:")
+    emit_epilogue(E, C, n_dma_k0(C))
+    if stamp:
+        emit_stamp(E, ACC_E)
+    E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
+    E.e(f"s_cbranch_scc1 {end}")
+    emit_load_record(E, "B")
+    emit_tile_prefetch(E, C)
+    E.e("s_barrier")                                 # every wave has waited for its LDS-DMA pieces inside the epilogue
+    E.e(f"s_branch {tile_loop}")
+    E.e(f"{end}:")
+    E.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if stamp:      # per wave: {kloop, epilogue, wait cycles, tiles, total cycles, total 100 MHz ticks} -> LDS table area (dead now)
+        E.e(f"s_memtime {sr(S['TMP64'], 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_sub_u32 {sr(T_START)}, {sr(S['TMP64'])}, {sr(T_START)}")
+        E.e(f"s_memrealtime {sr(S['TMP64'], 2)}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_sub_u32 {sr(R_START)}, {sr(S['TMP64'])}, {sr(R_START)}")
+        E.e("s_barrier")
+        for n, r in enumerate((ACC_K, ACC_E, ACC_W, S["TI"], T_START, R_START)):
+            E.e(f"v_mov_b32 {vr(8 + n)}, {sr(r)}")
+        E.e(f"v_mov_b32 {vr(14)}, 0")
+        E.e(f"v_mov_b32 {vr(15)}, 0")
+        E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 5")
+        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {TAB}")
+        E.e(f"v_mov_b32 {vr(16)}, {sr(S['TMP0'])}")
+        E.e(f"ds_write_b128 {vr(16)}, {vr(8, 4)}")
+        E.e(f"ds_write_b128 {vr(16)}, {vr(12, 4)} offset:16")
+        E.e("s_waitcnt lgkmcnt(0)")
+    return E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nb", type=int, default=4)
+    ap.add_argument("--stamp", action="store_true")
+    ap.add_argument("--budget", type=int, default=18)
+    ap.add_argument("--dma-step", type=float, default=Cfg.dma_step)
+    ap.add_argument("--dma-first", type=int, default=Cfg.dma_first)
+    ap.add_argument("--ablate", default="")
+    ap.add_argument("--pf-dist", type=int, default=Cfg.pf_dist)
+    a = ap.parse_args()
+    Cfg.dma_step, Cfg.dma_first, Cfg.ablate, Cfg.pf_dist = a.dma_step, a.dma_first, a.ablate, a.pf_dist
+    E = generate(a.nb, a.stamp, a.budget)
+    name = f"FG_GEMM_P{a.nb}"
+    out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} : do not edit", f"#define {name}_ASM \\"]
+    for ln in E.lines:
+        out.append('    "%s\\n\\t" \\' % ln)
+    out.append('    ""')
+    regs = [f'"v{i}"' for i in range(256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(SB, SB + NSREG + (4 if a.stamp else 0))]
+    out.append(f"#define {name}_CLOBBERS " + ", ".join(regs) + ', "vcc", "scc", "memory"')
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

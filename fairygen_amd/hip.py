@@ -29,6 +29,7 @@ _SIGNATURES = {
     "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
     "fg_gemm_bias_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "fg_gemm_epilogue_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
@@ -276,6 +277,36 @@ def gemm_bias(x, weight, bias, out=None):
     m, lda = x2.shape[0], x2.stride(0)
     out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
     _call("fg_gemm_bias_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 0, _stream(x))
+    return out
+
+
+def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=None):
+    """Linear on the persistent MFMA kernel.  residual=False: out = x @ weight^T + bias.  residual=True: `out` holds the residual
+    stream and becomes out + gate * (x @ weight^T + bias) (gate = vector gate_idx of `mod`, or 1 when mod is None), with the
+    reference's rounding points (GateModule, models/wan_video_dit.py:188-193)."""
+    _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
+    k = x.shape[-1]
+    n = weight.shape[0]
+    if weight.shape != (n, k) or not weight.is_contiguous() or bias.shape != (n,) or x.stride(-1) != 1:
+        raise HipLibraryError("gemm_epilogue: weight must be a contiguous (N, K) tensor, bias (N,), x dense in its last dim")
+    x2 = x.reshape(-1, k) if x.is_contiguous() else (x.squeeze(0) if x.dim() == 3 else x)
+    if x2.dim() != 2:
+        raise HipLibraryError("gemm_epilogue: strided input must be 2-D (rows, K) or (1, rows, K)")
+    m, lda = x2.shape[0], x2.stride(0)
+    if residual:
+        if out is None or not out.is_contiguous() or out.numel() != m * n:
+            raise HipLibraryError("gemm_epilogue: residual=True needs the contiguous residual stream as `out`")
+        _dev(out, "out")
+    else:
+        out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
+    if residual and mod is not None:
+        if mod.mod_rows not in (1, 2) or mod.c != n:
+            raise HipLibraryError("gemm_epilogue: the gate table must have 1 or 2 rows of N values")
+        _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 2, mod.vec(gate_idx),
+              mod.mod_rows, mod.ld, mod.first_rows, _stream(x))
+    else:
+        _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 3 if residual else 0, None,
+              1, n, 0, _stream(x))
     return out
 
 

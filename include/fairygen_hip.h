@@ -77,6 +77,19 @@ int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_
 int fg_gemm_bias_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
                       int64_t M, int64_t N, int64_t K, int flags, fg_stream_t stream);
 
+/* The same Linear with the DiT block's residual folded into the store (models/wan_video_dit.py:188-193 GateModule, :225-228):
+ *   mode 0: c = bf16(acc + bias)                                   (nn.Linear)
+ *   mode 2: c = bf16(c + bf16(gate * bf16(acc + bias)))            (x = x + gate * Linear(.), x read in place from c)
+ *   mode 3: c = bf16(c + bf16(acc + bias))                         (x = x + Linear(.))
+ * with the bf16 rounding points of the reference's three separate ops.  gate: a table of gate_rows (1 or 2) rows of N values, row
+ * stride gate_ld elements; with 2 rows, output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the
+ * others row 1.  N %% 256 == 0 or N %% 192 == 0, K %% 128 == 0.  Persistent kernel: one workgroup per CU walks a list of
+ * 256 x 256 or 256 x 192 output tiles (csrc/gen_gemm_p.py); the tile width is picked per shape so that the tile count fills
+ * whole rounds of the 256 CUs.  Every output element is one full-K fp32 accumulation in k order, whatever the tiling. */
+int fg_gemm_epilogue_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
+                          int64_t first_rows, fg_stream_t stream);
+
 /* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
  * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,
  * CrossAttention.forward :176-177 with cos==sin==NULL).  x has leading dimension ldx (so q/k slices of a
