@@ -82,7 +82,7 @@ class KernelTimer:
     blocks (wan_video_dit.gemm_bias*)."""
 
     def __init__(self):
-        self.attn, self.conv, self.gemm = [], [], []
+        self.attn, self.conv, self.gemm, self.gemm_own = [], [], [], []
 
     @staticmethod
     def _events():
@@ -91,7 +91,8 @@ class KernelTimer:
     def install(self):
         from fairygen_amd import hip, wan_video_dit
         self._orig = {"attention": hip.attention, "conv3d_cl": hip.conv3d_cl}
-        self._orig_gemm = {n: getattr(wan_video_dit, n) for n in ("gemm_bias", "gemm_bias_gelu", "gemm_bias_tuned")}
+        self._orig_gemm = {n: getattr(wan_video_dit, n) for n in ("gemm_bias", "gemm_bias_gelu", "gemm_bias_tuned", "gemm_bias_own",
+                                                                   "gemm_residual")}
         timer, lib = self, hip.load()
 
         def timed_attention(q, k, v, num_heads, out=None):
@@ -119,9 +120,17 @@ class KernelTimer:
                 s.record()
                 r = timer._orig_gemm[name](x, weight, bias)
                 e.record()
-                timer.gemm.append((x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], s, e))
+                (timer.gemm_own if name == "gemm_bias_own" else timer.gemm).append((x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], s, e))
                 return r
-            return fn
+
+            def fn_residual(x, a, weight, bias, mod=None, gate_idx=None):
+                s, e = timer._events()
+                s.record()
+                r = timer._orig_gemm[name](x, a, weight, bias, mod, gate_idx)
+                e.record()
+                timer.gemm_own.append((a.numel() // a.shape[-1], weight.shape[1], weight.shape[0], s, e))
+                return r
+            return fn_residual if name == "gemm_residual" else fn
         hip.attention, hip.conv3d_cl = timed_attention, timed_conv
         for n in self._orig_gemm:
             setattr(wan_video_dit, n, timed_gemm(n))
@@ -166,7 +175,14 @@ class KernelTimer:
         rec = [(2.0 * m * k * n, s.elapsed_time(e) * 1e-3) for m, k, n, s, e in self.gemm if m >= 1024]
         if rec:
             t, fl = sum(r[1] for r in rec), sum(r[0] for r in rec)
-            out.append({"kernel": "hipBLASLt bias-GEMMs of the DiT blocks (library; qkv, o, cross q/o, ffn.0+GELU, ffn.2)",
+            out.append({"kernel": "hipBLASLt bias-GEMMs of the DiT blocks (library: those not taken by gemm_p_kernel)",
+                        "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "launches": len(rec), "total_s": round(t, 3)})
+        rec = [(2.0 * m * k * n, s.elapsed_time(e) * 1e-3) for m, k, n, s, e in self.gemm_own]
+        if rec:
+            t, fl = sum(r[1] for r in rec), sum(r[0] for r in rec)
+            out.append({"kernel": "gemm_p_kernel (fg_gemm_epilogue_bf16: persistent hand-scheduled DiT GEMM; o / cross-o / ffn.2 with the "
+                                  "gate*y + x residual in the store, cross q)",
                         "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "launches": len(rec), "total_s": round(t, 3)})
         return out

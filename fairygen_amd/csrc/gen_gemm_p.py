@@ -24,7 +24,8 @@ SB = 36                                # s32..s34 are reserved by the compiler (
 S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, GD=16, WAVE=20, NK=21, LDA=22, LDC=23, KOFF=24, T=25, TI=26, TMP0=27,
                                 TMP1=28, TMP2=29, WDST=30, XDST=31, KW=32, FLAGS=33, FIRST=34, GLD=35, TMP64=36, ST1=38,
                                 GBASE=40, M0ROW=42, REC=44).items()}      # REC: 16 SGPRs of the current tile record
-NSREG = 60
+NSREG = 62                             # ... and the L2-prefetch lane shifts (s96, s97)
+PF_SX, PF_SW = SB + 60, SB + 61
 F0, F1 = 0, 32
 V_WRD, V_XRD = 64, 72
 V_DW, V_DX = 80, 88
@@ -48,10 +49,11 @@ OOB = 0x80000000
 
 
 class Cfg:
-    lbase = STAGE                        # the epilogue's transpose buffers live in stage 1 (the next tile's first slice goes to stage 0)
     dma_step = 2.0                       # MFMA gaps between two LDS-DMA pieces (--dma-step)
     dma_first = 1                        # gap of the first piece
-    pf_dist = 0                          # L2 prefetch distance in k-slices beyond the slice the step's LDS-DMA fetches (0 = off)
+    pf_coop = 1                          # 1: the CUs of an XCD that share an operand slice pull a part of its rows each (EXEC-masked): every
+                                         #    8th activation row (8 tiles of a row block), every 4th weight row; 2: activation rows only
+    pf_dist = 2                          # L2 prefetch distance in k-slices beyond the slice the step's LDS-DMA fetches (0 = off)
     ablate = ""                          # timing-only builds (wrong results): "nodma" = no LDS-DMA inside the k-loop, "samek", "l1"
 
     def __init__(self, nb):
@@ -59,6 +61,14 @@ class Cfg:
         self.g16 = nb * 4                # MFMAs per k-step
         self.gaps = 4 * self.g16         # MFMAs per K-step of 64
         self.npw = 2 * nb                # weight LDS-DMA pieces per wave per tile
+        # LDS ring of operand stages.  256-/192-column tiles: 2 stages of 64 KiB.  The 64-column tail tile moves 40 KiB per k-step
+        # for a quarter of the MFMAs, so with 2 stages its step would last one LDS-DMA round trip (measured: ~2 000 cycles, as long
+        # as a full tile's); its 40 KiB stages fit a ring of 3 and the DMA of slice t+2 has two steps to land.
+        self.ring = 3 if nb == 1 else 2
+        self.stage_bytes = 40960 if nb == 1 else STAGE
+        self.xoff = 8192 if nb == 1 else XOFF
+        # the epilogue's transpose buffers: stage 1 (2 stages: the next tile's first slice goes to stage 0) / above the tile table
+        self.lbase = STAGE if self.ring == 2 else TAB + 8192
         self.rs = nb * 64 + 16           # LDS row stride of the transpose buffer (bytes): a 32-row block of the wave's 128 x NB*32 part
         self.wsz = 32 * self.rs
 
@@ -67,7 +77,7 @@ def acc(ni, mi, j=0):
     return (ni * 4 + mi) * 16 + j
 
 
-def emit_setup(E, C):
+def emit_setup(E, C, first=True):
     """%0 kernarg-independent scalars: %0 wave, %1 K/64, %2 lda bytes, %3 ldc bytes, %4 K bytes, %5 flags, %6 first_rows (gate class)."""
     for n, name in enumerate(["WAVE", "NK", "LDA", "LDC", "KW", "FLAGS", "FIRST"]):
         E.e(f"s_mov_b32 {sr(S[name])}, %{n}")
@@ -75,8 +85,9 @@ def emit_setup(E, C):
         E.e(f"s_mov_b32 {sr(base + 3)}, 0x00020000")
     E.e(f"s_mul_i32 {sr(S['WDST'])}, {sr(S['WAVE'])}, {C.npw * 1024}")
     E.e(f"s_lshl_b32 {sr(S['XDST'])}, {sr(S['WAVE'])}, 13")
-    E.e(f"s_add_u32 {sr(S['XDST'])}, {sr(S['XDST'])}, {XOFF}")
-    E.e(f"s_mov_b32 {sr(S['TI'])}, 0")
+    E.e(f"s_add_u32 {sr(S['XDST'])}, {sr(S['XDST'])}, {C.xoff}")
+    if first:
+        E.e(f"s_mov_b32 {sr(S['TI'])}, 0")
     E.e(f"v_mov_b32 {vr(255)}, 0")
     E.nops(4)
     L, R, HH, SW, T0, T1, T2 = (V_T + i for i in range(7))
@@ -90,15 +101,16 @@ def emit_setup(E, C):
     E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {C.nb * 4096}")          # weight half of this wave
     E.e(f"s_and_b32 {sr(S['TMP1'])}, {sr(S['WAVE'])}, 1")
     E.e(f"s_lshl_b32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, 14")
-    E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {XOFF}")
+    E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {C.xoff}")
     for ks in range(4):
         E.e(f"v_or_b32 {vr(T1)}, {2 * ks}, {vr(HH)}")
         E.e(f"v_xor_b32 {vr(T1)}, {vr(T1)}, {vr(SW)}")
         E.e(f"v_lshl_add_u32 {vr(T1)}, {vr(T1)}, 4, {vr(T0)}")
         E.e(f"v_add_u32 {vr(V_WRD + ks)}, {sr(S['TMP0'])}, {vr(T1)}")
         E.e(f"v_add_u32 {vr(V_XRD + ks)}, {sr(S['TMP1'])}, {vr(T1)}")
-        E.e(f"v_add_u32 {vr(V_WRD + 4 + ks)}, {STAGE}, {vr(V_WRD + ks)}")
-        E.e(f"v_add_u32 {vr(V_XRD + 4 + ks)}, {STAGE}, {vr(V_XRD + ks)}")
+        second = C.stage_bytes * (2 if C.ring == 3 else 1)      # ring of 3: set 0 serves stages 0 and 1 (immediate offset), set 1 stage 2
+        E.e(f"v_add_u32 {vr(V_WRD + 4 + ks)}, {second}, {vr(V_WRD + ks)}")
+        E.e(f"v_add_u32 {vr(V_XRD + 4 + ks)}, {second}, {vr(V_XRD + ks)}")
     # LDS-DMA source offsets (piece i of this wave: tile rows 8*(w*P + i) .. +7)
     E.e(f"v_lshrrev_b32 {vr(T0)}, 3, {vr(L)}")
     E.e(f"v_lshrrev_b32 {vr(T1)}, 4, {vr(L)}")
@@ -149,19 +161,19 @@ def emit_setup(E, C):
     E.e(f"v_add_u32 {vr(V_RROW)}, {sr(S['TMP1'])}, {vr(I4)}")
     E.e(f"v_lshlrev_b32 {vr(V_GOFF)}, 4, {vr(I15)}")
     E.e(f"v_add_u32 {vr(V_GOFF)}, {sr(S['TMP0'])}, {vr(V_GOFF)}")
-    if C.nb == 3:      # lanes 12..15 of every 16 have no columns: their global accesses go out of range (loads 0, stores dropped)
-        E.e(f"v_cmp_le_u32 vcc, 12, {vr(I15)}")
+    if C.nb < 4:       # lanes 4*NB..15 of every 16 have no columns: their global accesses go out of range (loads 0, stores dropped)
+        E.e(f"v_cmp_le_u32 vcc, {4 * C.nb}, {vr(I15)}")
         E.e(f"v_mov_b32 {vr(T2)}, {OOB}")
         E.e("s_nop 1")
         E.e(f"v_cndmask_b32 {vr(V_GOFF)}, {vr(V_GOFF)}, {vr(T2)}, vcc")
     E.e(f"v_mul_lo_u32 {vr(V_SOFF)}, {vr(V_RROW)}, {sr(S['LDC'])}")
     E.e(f"v_add_u32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(V_GOFF)}")
-    if C.nb == 3:
+    if C.nb < 4:
         E.e(f"v_cndmask_b32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(T2)}, vcc")
     E.nops(2)
 
 
-ACC_K, ACC_E, ACC_W, T_START, R_START = S["ST1"] + 1, SB + 60, SB + 61, SB + 62, SB + 63     # --stamp only (s96..s99)
+ACC_K, ACC_E, ACC_W, T_START, R_START = S["ST1"] + 1, SB + 62, SB + 63, SB + 64, SB + 65     # --stamp only (s98..s101)
 
 
 def emit_stamp(E, acc):
@@ -193,6 +205,9 @@ def emit_load_record(E, part):
         E.e(f"s_mov_b32 {sr(S['XD'] + 2)}, {sr(S['REC'] + 8)}")
         E.e(f"s_mov_b64 {sr(S['WD'], 2)}, {sr(S['REC'] + 2, 2)}")
         E.e(f"s_mov_b32 {sr(S['WD'] + 2)}, {sr(S['REC'] + 13)}")
+        # cooperative L2 prefetch: this CU pulls activation rows l % 8 == record[14] and weight rows l % 4 == record[15]
+        E.e(f"s_mov_b32 {sr(PF_SX)}, {sr(S['REC'] + 14)}")
+        E.e(f"s_mov_b32 {sr(PF_SW)}, {sr(S['REC'] + 15)}")
     else:
         E.e(f"s_mov_b64 {sr(S['CD'], 2)}, {sr(S['REC'] + 4, 2)}")
         E.e(f"s_mov_b32 {sr(S['CD'] + 2)}, {sr(S['REC'] + 9)}")
@@ -205,7 +220,7 @@ def emit_load_record(E, part):
 def dma_piece(C, op, i, stage):
     base, dst, rs = (V_DW, S["WDST"], S["WD"]) if op == "W" else (V_DX, S["XDST"], S["XD"])
     src = vr(base + i) if C.ablate != "l1" else vr(255)          # l1 (timing only): every lane reads the first 16 bytes of the tile
-    return [f"s_add_u32 m0, {sr(dst)}, {stage * STAGE + i * 1024}",
+    return [f"s_add_u32 m0, {sr(dst)}, {stage * C.stage_bytes + i * 1024}",
             "s_nop 0",
             f"buffer_load_dwordx4 {src}, {sr(rs, 4)}, {sr(S['KOFF'])} offen lds"]
 
@@ -219,10 +234,29 @@ def prefetch(C, op, slices_ahead):
     return f"buffer_load_dword {vr(V_PD)}, {vr(base)}, {sr(rs, 4)}, {sr(S['KOFF'])} offen offset:{128 * slices_ahead}"
 
 
-def frag_read(op, blk, fset, stage, ks):
+def prefetch_lines(C, op, slices_ahead):
+    if not C.pf_coop or (C.nb == 1 and op == "W"):      # a 64-column tail piece shares its weight rows with nobody
+        return [prefetch(C, op, slices_ahead)]
+    if C.nb == 1:      # ... and its activation rows with the 3 other pieces of its tile: every 4th row each
+        pat, sh = "0x11111111", PF_SX
+    else:
+        pat, sh = ("0x01010101", PF_SX) if op == "X" else ("0x11111111", PF_SW)
+    return [f"s_mov_b32 exec_lo, {pat}", f"s_mov_b32 exec_hi, {pat}", f"s_lshl_b64 exec, exec, {sr(sh)}",
+            prefetch(C, op, slices_ahead), "s_mov_b64 exec, -1"]
+
+
+def pf_ops(C):
+    return ("X",) if C.pf_coop == 2 else ("W", "X")
+
+
+def frag_read(C, op, blk, fset, stage, ks):
     dst = fset + (0 if op == "W" else 16) + 4 * blk
-    base = (V_WRD if op == "W" else V_XRD) + 4 * stage + ks
-    return f"ds_read_b128 {vr(dst, 4)}, {vr(base)} offset:{blk * 4096}"
+    if C.ring == 3:      # base set 0 = stage 0 (stage 1 through the immediate offset), set 1 = stage 2
+        bset, extra = (1, 0) if stage == 2 else (0, stage * C.stage_bytes)
+    else:
+        bset, extra = stage, 0
+    base = (V_WRD if op == "W" else V_XRD) + 4 * bset + ks
+    return f"ds_read_b128 {vr(dst, 4)}, {vr(base)} offset:{blk * 4096 + extra}"
 
 
 def mfma(ni, mi, fset, zero_c=False):
@@ -245,16 +279,17 @@ def build_iteration(E, C, stage, first, budget):
                     earliest = g16 * busy_blk + (4 * blk + 3 if op == "W" else 4 * (C.nb - 1) + blk) + 2
                 need = g16 * need_blk + (4 * blk if op == "W" else blk)
                 deadline = min(need - 4, C.gaps - 4)
-                add(Item(f"rd{ks}{op}{blk}", [frag_read(op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest), lds=1))
+                add(Item(f"rd{ks}{op}{blk}", [frag_read(C, op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest), lds=1))
     pieces = [("W", i) for i in range(C.npw)] + [("X", i) for i in range(8)]
+    dma_step = min(C.dma_step, 0.5 * C.gaps / len(pieces))       # all pieces inside the first half of the step
     for n, (op, i) in enumerate(pieces if C.ablate != "nodma" else []):
-        g0 = C.dma_first + int(n * C.dma_step)
-        add(Item(f"dma{op}{i}", dma_piece(C, op, i, stage ^ 1), 12, earliest=g0, deadline=g0 + 8))
+        g0 = C.dma_first + int(n * dma_step)
+        add(Item(f"dma{op}{i}", dma_piece(C, op, i, (stage + C.ring - 1) % C.ring), 12, earliest=g0, deadline=g0 + 8))
     n_pf = 0
     if C.pf_dist and C.ablate != "nodma":      # after every LDS-DMA piece in program order: the step's wait is vmcnt(n_pf)
-        last = C.dma_first + int((len(pieces) - 1) * C.dma_step) + 8
-        for n, op in enumerate(("W", "X")):
-            add(Item(f"pf{op}", [prefetch(C, op, C.pf_dist)], 8, earliest=last + 1 + 2 * n, deadline=min(last + 9 + 2 * n, C.gaps - 1)))
+        last = C.dma_first + int((len(pieces) - 1) * dma_step) + 8
+        for n, op in enumerate(pf_ops(C)):
+            add(Item(f"pf{op}", prefetch_lines(C, op, C.pf_dist), 8, earliest=min(last + 1 + 2 * n, C.gaps - 2), deadline=min(last + 9 + 2 * n, C.gaps - 1)))
             n_pf += 1
     gaps, load = schedule(items, C.gaps, budget)
     lds_issued, lds_done, done_at = 0, 0, {}
@@ -277,44 +312,52 @@ def build_iteration(E, C, stage, first, budget):
                 done_at[it.name] = lds_issued
     if C.ablate != "samek":                        # samek (timing only): every k-step re-reads the tile's second slice (L2-resident)
         E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
-    E.e(f"s_waitcnt vmcnt({n_pf}) lgkmcnt(0)")
+    # ring of 2: everything but the prefetches; ring of 3: this step's pieces (slice t+2) may stay in flight, slice t+1 has landed
+    n_keep = n_pf + (len(pieces) if C.ring == 3 and C.ablate != "nodma" else 0)
+    E.e(f"s_waitcnt vmcnt({n_keep}) lgkmcnt(0)")
     E.e("s_barrier")
     return load
 
 
 def emit_kloop(E, C, budget):
-    """Tile's k-slice 0 is in stage 0 and visible; KOFF = 128."""
+    """Tile's k-slice 0 is in stage 0 and visible (ring of 3: slice 1 is on its way to stage 1); KOFF = the next slice to fetch."""
     loop, done = E.label("kloop"), E.label("kdone")
     E.e(f"s_mov_b32 {sr(S['T'])}, 1")
     build_iteration(E, C, 0, True, budget)
     E.e(f"s_cmp_ge_u32 {sr(S['T'])}, {sr(S['NK'])}")
     E.e(f"s_cbranch_scc1 {done}")
     E.e(f"{loop}:")
-    for stage in (1, 0):
+    order = [(st + 1) % C.ring for st in range(C.ring)]           # stages 1, 0 / 1, 2, 0
+    for stage in order:
         build_iteration(E, C, stage, False, budget)
         E.e(f"s_add_u32 {sr(S['T'])}, {sr(S['T'])}, 1")
         E.e(f"s_cmp_ge_u32 {sr(S['T'])}, {sr(S['NK'])}")
-        E.e(f"s_cbranch_scc1 {done}" if stage == 1 else f"s_cbranch_scc0 {loop}")
+        E.e(f"s_cbranch_scc1 {done}" if stage != order[-1] else f"s_cbranch_scc0 {loop}")
     E.e(f"{done}:")
     for idx in range(C.g16):
         E.e(mfma(idx >> 2, idx & 3, F1))
+    if C.ring == 3:      # the last steps fetched past the end of K: those pieces must be down before the next tile's slices target the ring
+        E.e("s_waitcnt vmcnt(0)")
 
 
 def n_dma_k0(C):
-    return C.npw + 8 + 2 * C.pf_dist
+    return (C.npw + 8) * (C.ring - 1) + len(pf_ops(C)) * C.pf_dist
 
 
 def emit_dma_k0(E, C):
-    """The tile's first k-slice -> stage 0, and the L2 prefetch of the slices the first pf_dist steps will fetch."""
-    E.e(f"s_mov_b32 {sr(S['KOFF'])}, 0")
-    for op, n in (("W", C.npw), ("X", 8)):
-        for i in range(n):
-            for ln in dma_piece(C, op, i, 0):
-                E.e(ln)
+    """The tile's first k-slice -> stage 0 (ring of 3: and the second -> stage 1), and the L2 prefetch of the slices the first
+    pf_dist steps will fetch."""
+    for sl in range(C.ring - 1):
+        E.e(f"s_mov_b32 {sr(S['KOFF'])}, {128 * sl}")
+        for op, n in (("W", C.npw), ("X", 8)):
+            for i in range(n):
+                for ln in dma_piece(C, op, i, sl):
+                    E.e(ln)
     for d in range(1, C.pf_dist + 1):
-        for op in ("W", "X"):
-            E.e(prefetch(C, op, d))
-    E.e(f"s_mov_b32 {sr(S['KOFF'])}, 128")
+        for op in pf_ops(C):
+            for ln in prefetch_lines(C, op, d):
+                E.e(ln)
+    E.e(f"s_mov_b32 {sr(S['KOFF'])}, {128 * (C.ring - 1)}")
 
 
 def qoff(q):
@@ -437,10 +480,11 @@ def emit_epilogue(E, C, n_dma):
     E.e(f"{done}:")
 
 
-def generate(nb, stamp, budget):
-    C = Cfg(nb)
-    E = Emitter()
-    emit_setup(E, C)
+def emit_program(E, C, stamp, budget, first):
+    """One body: walks tile records from TI on until a record with valid = 0, and leaves TI on the record after it.  first: the
+    body that starts the kernel (TI = 0, stamp counters cleared); a later body re-derives every lane constant for its own tile
+    width and goes on reading the table where the previous one stopped."""
+    emit_setup(E, C, first)
     # %7 gate base (64-bit: row 0 of the gate vector, column 0), %8 gate row stride in bytes (0: one row), %9 bytes of the gate table
     E.e(f"s_mov_b64 {sr(S['GBASE'], 2)}, %7")
     E.e(f"s_mov_b32 {sr(S['GLD'])}, %8")
@@ -449,7 +493,7 @@ def generate(nb, stamp, budget):
     end = E.label("pend")
     tile_loop = E.label("ptile")
     nodma = E.label("pnodma")
-    if stamp:
+    if stamp and first:
         for r in (ACC_K, ACC_E, ACC_W):
             E.e(f"s_mov_b32 {sr(r)}, 0")
         E.e(f"s_memrealtime {sr(S['TMP64'], 2)}")
@@ -492,7 +536,16 @@ def generate(nb, stamp, budget):
     E.e(f"s_branch {tile_loop}")
     E.e(f"{end}:")
     E.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    if stamp:      # per wave: {kloop, epilogue, wait cycles, tiles, total cycles, total 100 MHz ticks} -> LDS table area (dead now)
+    E.e("s_barrier")                                 # nobody is still inside this body's LDS when the next one (or the stamp dump) starts
+    E.e(f"s_add_u32 {sr(S['TI'])}, {sr(S['TI'])}, 1")            # past the terminator
+
+
+def generate(nb, stamp, budget, tail=0):
+    E = Emitter()
+    emit_program(E, Cfg(nb), stamp, budget, True)
+    if tail:      # the tiles of the last, partly filled round, cut into 256 x tail*64 pieces (the table's second list)
+        emit_program(E, Cfg(tail), stamp, budget, False)
+    if stamp:      # per wave: {kloop, epilogue, wait cycles, records passed, total cycles, total 100 MHz ticks} -> LDS table area (dead now)
         E.e(f"s_memtime {sr(S['TMP64'], 2)}")
         E.e("s_waitcnt lgkmcnt(0)")
         E.e(f"s_sub_u32 {sr(T_START)}, {sr(S['TMP64'])}, {sr(T_START)}")
@@ -516,17 +569,19 @@ def generate(nb, stamp, budget):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nb", type=int, default=4)
+    ap.add_argument("--tail", type=int, default=0, help="second body for the table's second tile list: 256 x TAIL*64 tiles")
     ap.add_argument("--stamp", action="store_true")
     ap.add_argument("--budget", type=int, default=18)
     ap.add_argument("--dma-step", type=float, default=Cfg.dma_step)
     ap.add_argument("--dma-first", type=int, default=Cfg.dma_first)
     ap.add_argument("--ablate", default="")
     ap.add_argument("--pf-dist", type=int, default=Cfg.pf_dist)
+    ap.add_argument("--pf-coop", type=int, default=Cfg.pf_coop)
     a = ap.parse_args()
-    Cfg.dma_step, Cfg.dma_first, Cfg.ablate, Cfg.pf_dist = a.dma_step, a.dma_first, a.ablate, a.pf_dist
-    E = generate(a.nb, a.stamp, a.budget)
-    name = f"FG_GEMM_P{a.nb}"
-    out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} : do not edit", f"#define {name}_ASM \\"]
+    Cfg.dma_step, Cfg.dma_first, Cfg.ablate, Cfg.pf_dist, Cfg.pf_coop = a.dma_step, a.dma_first, a.ablate, a.pf_dist, a.pf_coop
+    E = generate(a.nb, a.stamp, a.budget, a.tail)
+    name = f"FG_GEMM_P{a.nb}{a.tail or ''}"
+    out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} --tail {a.tail} : do not edit", f"#define {name}_ASM \\"]
     for ln in E.lines:
         out.append('    "%s\\n\\t" \\' % ln)
     out.append('    ""')

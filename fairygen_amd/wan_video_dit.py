@@ -9,6 +9,8 @@ arithmetic is in ``forward_tokens`` below, built from ``fairygen_amd.hip`` kerne
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -50,6 +52,29 @@ def gemm_bias_gelu(x, weight, bias):
 
 def gemm_bias_tuned(x, weight, bias):
     return tuning.linear(x, weight, bias)      # table: better hipBLASLt solution at the multi-GPU shard sizes
+
+
+# The DiT Linears that run on this repo's own persistent MFMA kernel (fg_gemm_epilogue_bf16, csrc/gen_gemm_p.py) — also seams for
+# bench.py.  FAIRYGEN_GEMM = "fused" (default): the 3072 x 3072 projections — self-attention o and cross-attention o, whose output
+# goes straight into the residual stream (the GateModule add happens in the GEMM's store, so the following LayerNorm reads x once
+# instead of x and y), and the cross-attention q; "fused+ffn2": ffn.2 with gate_mlp too (measured at parity with the library +
+# residual kernel: K = 14336 makes the left-over 64-column pieces of the last round expensive); "all": qkv as well; "lib":
+# everything on hipBLASLt.
+GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "fused")
+
+
+def own_gemm_ok(rows, n, k):
+    """Shapes the persistent kernel takes AND fills the chip with: 256-column tiles, at least two rounds of the 256 CUs."""
+    return GEMM_BACKEND != "lib" and n % 256 == 0 and k % 128 == 0 and ((rows + 255) // 256) * (n // 256) >= 512
+
+
+def gemm_bias_own(x, weight, bias):
+    return hip.gemm_epilogue(x, weight, bias)
+
+
+def gemm_residual(x, a, weight, bias, mod=None, gate_idx=None):
+    """x (the residual stream, contiguous, updated in place) += gate * Linear(a); gate = vector gate_idx of mod, or 1."""
+    return hip.gemm_epilogue(a, weight, bias, out=x, residual=True, mod=mod, gate_idx=gate_idx)
 
 
 class RMSNorm(nn.Module):
@@ -325,7 +350,13 @@ class WanModel(nn.Module):
                 w8 = blk.fp8_weights(fp8)
                 lin = lambda t, j, bias, act=None: self._scaled_linear(*hip.fp8_quant_rows(t, act), w8[j], bias)      # noqa: E731
             # --- self attention (reference :139-146)
-            qkv = gemm_bias(h, wqkv, bqkv) if fp8 is None else lin(h, 0, bqkv)
+            own = fp8 is None and not hot and mod.mod_rows in (1, 2)
+            if fp8 is not None:
+                qkv = lin(h, 0, bqkv)
+            elif GEMM_BACKEND == "all" and own and own_gemm_ok(h.shape[1], 3 * c, c):
+                qkv = gemm_bias_own(h, wqkv, bqkv)
+            else:
+                qkv = gemm_bias(h, wqkv, bqkv)
             if hot:
                 for j, nm in enumerate(("q", "k", "v")):
                     self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
@@ -360,14 +391,18 @@ class WanModel(nn.Module):
                 yield i
                 k, v = pending.wait()
                 a = sa.attn(q, k, v)
-            y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
-            if hot:
-                self._hot(f"blocks.{i}.self_attn.o", a, y)
             # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
-            x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+            if own and own_gemm_ok(a.shape[1], c, c):      # the gated add happens in the GEMM's store
+                x = gemm_residual(x, a, sa.o.weight, sa.o.bias, mod, 2)
+                h = hip.ln_affine(x, blk.norm3.weight, blk.norm3.bias, eps)
+            else:
+                y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
+                if hot:
+                    self._hot(f"blocks.{i}.self_attn.o", a, y)
+                x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
             # --- cross attention (reference :170-185)
             if fp8 is None:
-                qc = gemm_bias(h, ca.q.weight, ca.q.bias)
+                qc = gemm_bias_own(h, ca.q.weight, ca.q.bias) if own and own_gemm_ok(h.shape[1], c, c) else gemm_bias(h, ca.q.weight, ca.q.bias)
                 kvc = gemm_bias(context, wkv_c, bkv_c)
             else:
                 qc = lin(h, 2, ca.q.bias)
@@ -379,11 +414,15 @@ class WanModel(nn.Module):
             qc = hip.rmsnorm_rope(qc, ca.norm_q.weight, nh, eps)
             kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
             ac = ca.attn(qc, kc, kvc[..., c:])
-            y = gemm_bias(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
-            if hot:
-                self._hot(f"blocks.{i}.cross_attn.o", ac, y)
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
-            x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
+            if own and own_gemm_ok(ac.shape[1], c, c):
+                x = gemm_residual(x, ac, ca.o.weight, ca.o.bias)
+                h = hip.ln_modulate(x, mod, 3, 4, eps)
+            else:
+                y = gemm_bias(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
+                if hot:
+                    self._hot(f"blocks.{i}.cross_attn.o", ac, y)
+                x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
             # --- ffn (reference :208-209,228)
             if fp8 is not None:      # ffn.0 -> bf16, GELU(tanh) fused into the quantisation of ffn.2's input
                 pre = lin(h, 5, blk.ffn[0].bias)
@@ -397,6 +436,11 @@ class WanModel(nn.Module):
                 f = gemm_bias_gelu(h, blk.ffn[0].weight, blk.ffn[0].bias)
             else:
                 f = hip.activation(gemm_bias(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
+            if own and GEMM_BACKEND in ("fused+ffn2", "all") and own_gemm_ok(f.shape[1], c, f.shape[2]):      # x += gate_mlp * ffn.2(f) in the store
+                x = gemm_residual(x, f, blk.ffn[2].weight, blk.ffn[2].bias, mod, 5)
+                if i + 1 < len(blocks):
+                    h = hip.ln_modulate(x, mods[i + 1], 0, 1, eps, out=h)
+                continue
             if fp8 is None:
                 y = gemm_bias_tuned(f, blk.ffn[2].weight, blk.ffn[2].bias)
             if hot and f"blocks.{i}.ffn.2" in self.hot_loras:

@@ -98,6 +98,42 @@ def test_fused_residual_norms(hip):
     assert_close_bf16(no, wan_dit.layer_norm(x2, 1e-6, w, b), 1.0, "res+affine", mag=b)
 
 
+@pytest.mark.parametrize("M,K,N", [(700, 256, 768),       # 9 tiles: every one a 64-column tail piece (second body, ring of 3)
+                                   (4200, 512, 4096),     # 272 tiles: one full round of 256-column tiles + cut tail, ragged last rows
+                                   (600, 384, 576),       # 192-column tiles (N % 256 != 0)
+                                   (10500, 128, 2048)])   # 336 tiles: left-over tiles NOT cut (10 per XCD), K = one step pair, 4 rows in the last row tile
+def test_gemm_epilogue(hip, M, K, N):
+    """fg_gemm_epilogue_bf16 (persistent MFMA GEMM, nn.Linear of the DiT blocks: models/wan_video_dit.py:130-133,208-209): error to
+    the fp32 product <= 2x the error of the reference's own bf16 op (CPU F.linear) + floor; the residual modes (GateModule :188-193,
+    :225-228) must equal x + gate * y built from the kernel's own y with the reference's two bf16 roundings, bit for bit."""
+    x, w, b = seeded((1, M, K), 41), seeded((N, K), 42, scale=0.05), seeded((N,), 43, scale=0.2)
+    ref32 = F.linear(x.float(), w.float(), b.float())
+    ref16 = F.linear(x, w, b)
+    y = hip.gemm_epilogue(dev(x), dev(w), dev(b))
+    assert y.shape == (1, M, N)
+    err, ref_err = (y.float().cpu() - ref32).abs().max().item(), (ref16.float() - ref32).abs().max().item()
+    assert err <= 2 * ref_err + 1e-3, f"gemm {M}x{K}x{N}: {err} vs reference bf16 error {ref_err}"
+    assert (y.cpu() != ref16).float().mean().item() < 0.02          # same rounding almost everywhere (fp32 summation order differs)
+    res = seeded((1, M, N), 44)
+    first = 130
+    table = seeded((2, 6, N), 45)
+    idx = (torch.arange(M) >= first).long()
+    got = hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True, mod=hip.ModTable(dev(table), first), gate_idx=5)
+    assert torch.equal(got.cpu(), res + table[idx, 5].unsqueeze(0) * y.cpu())
+    got = hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True, mod=hip.ModTable(dev(table[:1].contiguous())), gate_idx=2)
+    assert torch.equal(got.cpu(), res + table[0, 2] * y.cpu())
+    got = hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True)
+    assert torch.equal(got.cpu(), res + y.cpu())
+    # strided input rows (a column slice of a wider tensor), as the fused QKV output is consumed elsewhere
+    wide = seeded((1, M, K + 64), 46)
+    y2 = hip.gemm_epilogue(dev(wide)[..., :K], dev(w), dev(b))
+    assert torch.equal(y2.cpu(), hip.gemm_epilogue(dev(wide[..., :K].contiguous()), dev(w), dev(b)).cpu())
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_epilogue(dev(x), dev(w)[:, : K - 64].contiguous(), dev(b))          # K mismatch
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_epilogue(x, w, b)                                                   # CPU tensors: no fallback
+
+
 @pytest.mark.parametrize("heads,C,grid", [(24, 3072, (2, 3, 5)), (2, 256, (3, 4, 4))])
 def test_rmsnorm_rope(hip, heads, C, grid):
     f, h, w_ = grid

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../fairygen_amd/csrc"
 name=$1; genargs=$2; extra=$3
 mkdir -p build/ab/ginc_$name
 cp build/gemm_w4_asm.inc build/ab/ginc_$name/
-python3 gen_gemm_p.py --nb 4 $genargs > build/ab/ginc_$name/gemm_p4_asm.inc
+python3 gen_gemm_p.py --nb 4 --tail 1 $genargs > build/ab/ginc_$name/gemm_p41_asm.inc
 python3 gen_gemm_p.py --nb 3 $genargs > build/ab/ginc_$name/gemm_p3_asm.inc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wall -Wno-unused-function -Ibuild/ab/ginc_$name $extra -x hip -c dit_gemm.hip -o build/ab/dit_gemm_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/libfgg_$name.so build/capi.cpp.o build/dit_elementwise.hip.o build/attention.hip.o build/ab/dit_gemm_$name.o build/vae_conv.hip.o build/vae_ops.hip.o build/text_encoder.hip.o build/fp8_linear.hip.o

@@ -118,9 +118,9 @@ def main():
             buf = np.zeros((256, 4, 8), dtype=np.uint32)
             stamp_p.fg_gemm_stamp_read(buf.ctypes.data_as(ctypes.c_void_p), st)
             w0 = buf[:, 0, :].astype(np.float64)          # wave 0 of every workgroup: kloop, epilogue, wait, tiles, total, ticks
-            tiles = np.maximum(w0[:, 3], 1)
+            tiles = np.maximum(w0[:, 3] - 2, 1)          # records passed, minus the two list terminators
             clk = np.median(w0[:, 4] / np.maximum(w0[:, 5], 1) * 100)
-            print(f"   p stamp ({'equal' if torch.equal(o2, outp) else 'DIFFERENT'} output): tiles/CU {w0[:, 3].min():.0f}-{w0[:, 3].max():.0f}; per tile: "
+            print(f"   p stamp ({'equal' if torch.equal(o2, outp) else 'DIFFERENT'} output): tiles/CU {tiles.min():.0f}-{tiles.max():.0f}; per tile: "
                   f"k-loop {np.median(w0[:, 0] / tiles):.0f} ({np.median(w0[:, 0] / tiles) / (k // 64):.0f} per 64-k step), epilogue "
                   f"{np.median(w0[:, 1] / tiles):.0f}, wait {np.median(w0[:, 2] / tiles):.0f} cycles; kernel {np.median(w0[:, 4]):.0f} cycles "
                   f"(max {w0[:, 4].max():.0f}), clock {clk:.0f} MHz; sum of parts {np.median((w0[:, 0] + w0[:, 1] + w0[:, 2])):.0f}", flush=True)
