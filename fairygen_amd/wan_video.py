@@ -15,6 +15,8 @@ Extensions (the only additions to the call surface, both optional):
     through ``pipe.vae.encode`` (VAE38 encoder on the same HIP kernels) exactly like the reference.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 from PIL import Image
@@ -507,9 +509,16 @@ class WanVideoPipeline(torch.nn.Module):
             raise NotImplementedError("cfg_merge=True batches both branches into one forward; a cfg_parallel=2 layout gives "
                                       "each branch its own ranks — use one or the other")
         interleave = sharded and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split and not cfg_merge
+        # the two CFG forwards of a step differ only in the context: what precedes block 0's cross-attention is computed once
+        # (WanModel.forward_tokens_steps, cfg_prefix); not with TeaCache (per-branch state) or sliding windows (many forwards)
+        share = (CFG_SHARE_PREFIX and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split and not cfg_merge
+                 and inputs_posi.get("tea_cache") is None and inputs_nega.get("tea_cache") is None
+                 and shared.get("sliding_window_size") is None)
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
+            if share:
+                shared["cfg_prefix"] = {}
             if cfg_merge:
                 # reference :296-299: one call on the batched context, then chunk (with cfg_scale == 1 the reference still
                 # runs the batch of two and keeps both halves' mean-free "posi": it uses the whole (2, ...) tensor — not a
@@ -538,6 +547,9 @@ class WanVideoPipeline(torch.nn.Module):
             if first is not None:
                 latents[:, :, 0:1] = first
         return latents
+
+
+CFG_SHARE_PREFIX = os.environ.get("FAIRYGEN_CFG_SHARE", "1") != "0"
 
 
 def inputs_posi_ctx(d):
@@ -632,7 +644,7 @@ def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window
 
 def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
                              sequence_shard=None, gather_output=True, tea_cache=None, sliding_window_size=None,
-                             sliding_window_stride=None, **kwargs):
+                             sliding_window_stride=None, cfg_prefix=None, **kwargs):
     """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction, or
     with gather_output=False the head output of this rank's tokens (1, n_local, out_dim*prod(patch)) and the grid).
 
@@ -648,11 +660,12 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         if tea_cache is not None:
             raise NotImplementedError("TeaCache is per CFG branch; the merged call has none (the reference drops it too)")
         outs = []
+        prefix = {} if (CFG_SHARE_PREFIX and sliding_window_size is None) else None      # the elements differ only in their context
         for b in range(context.shape[0]):
             outs.append((yield from model_fn_wan_video_steps(
                 dit, latents=latents, timestep=timestep, context=context[b:b + 1], sequence_shard=sequence_shard,
                 fuse_vae_embedding_in_latents=fuse_vae_embedding_in_latents, gather_output=gather_output,
-                sliding_window_size=sliding_window_size, sliding_window_stride=sliding_window_stride)))
+                sliding_window_size=sliding_window_size, sliding_window_stride=sliding_window_stride, cfg_prefix=prefix)))
         if not gather_output:
             return torch.cat([o[0] for o in outs], dim=0), outs[0][1]
         return torch.cat(outs, dim=0)
@@ -695,13 +708,14 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         skip = tea_cache is not None and tea_cache.check(dit, x_loc, TimeModulation(mod_rows_t, first_rows, n))
         out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
                                                       (cos[lo:hi].contiguous(), sin[lo:hi].contiguous() if sin is not None else None), sequence_shard, n,
-                                                      tea_cache, skip)
+                                                      tea_cache, skip, cfg_prefix if tea_cache is None else None)
         if not gather_output:
             return out_loc, (f, h, w)
         out = sequence_shard.all_gather_tokens(out_loc, n)
     else:
         skip = tea_cache is not None and tea_cache.check(dit, x, TimeModulation(mod_rows_t, first_rows, n))
-        out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin), None, None, tea_cache, skip)
+        out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin), None, None, tea_cache, skip,
+                                                  cfg_prefix if tea_cache is None else None)
         if not gather_output:
             return out, (f, h, w)
     return dit.unpatchify(out, (f, h, w))

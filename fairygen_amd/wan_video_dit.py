@@ -305,11 +305,73 @@ class WanModel(nn.Module):
         x = x.view(b, f, h, w, px, py, pz, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
         return x.reshape(b, self.out_dim, f * px, h * py, w * pz)
 
+    def _self_attention_steps(self, i, blk, mod, x, h, cos, sin, shard, shard_total, own, lin):
+        """Block i's self-attention half (reference :139-146, :225-226): h = modulate(norm1(x)) in; returns the residual stream after
+        x += gate_msa * o(attn(...)) and h = norm3(x).  Yields right after each exchange of a token-sharded run has been started.
+        lin: the fp8 Linear closure of the block (None in bf16 mode)."""
+        c, nh, eps = self.dim, self.num_heads, self.eps
+        fp8 = self.fp8_dtype if lin is not None else None
+        hot = bool(self.hot_loras)
+        sharded = shard is not None and shard.active
+        wqkv, bqkv, _, _ = blk.fused_weights()
+        sa = blk.self_attn
+        if fp8 is not None:
+            qkv = lin(h, 0, bqkv)
+        elif GEMM_BACKEND == "all" and own and own_gemm_ok(h.shape[1], 3 * c, c):
+            qkv = gemm_bias_own(h, wqkv, bqkv)
+        else:
+            qkv = gemm_bias(h, wqkv, bqkv)
+        if hot:
+            for j, nm in enumerate(("q", "k", "v")):
+                self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
+        v = qkv[..., 2 * c:]
+        if not sharded:
+            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+            a = sa.attn(q, k, v)
+        elif shard.attn_mode == "ulysses":
+            # token shard -> head shard (all N tokens of 24/P heads), attention, head shard -> token shard.  The
+            # norm+RoPE kernels and one strided copy write q | k | v straight into the all-to-all send buffer.
+            n_loc, p_, size = x.shape[1], shard.world_size, shard.chunk(shard_total)
+            g = c // nh * shard.heads_local(nh)
+            send = shard.ulysses_send_buffer(shard_total, c, qkv, n_loc)           # (P, chunk, 3, g)
+            flat, layout = send.view(-1), (g, size * 3 * g, 3 * g)
+            hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin, grouped=(flat, *layout))
+            hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin, grouped=(flat[g:], *layout))
+            hip.copy_groups(qkv.view(-1)[2 * c:], g, 3 * c, flat[2 * g:], size * 3 * g, 3 * g, p_, n_loc, g)
+            pending = shard.ulysses_exchange_async(send, shard_total)
+            yield i
+            qg, kg, vg = pending.wait()
+            o_full = shard.ulysses_out_buffer(shard_total, g, qkv)
+            hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0))
+            pending = shard.ulysses_out_async(o_full, shard_total, n_loc)
+            yield i
+            a = torch.empty((1, n_loc, c), dtype=qkv.dtype, device=qkv.device)
+            hip.copy_groups(pending.wait_blocks().view(-1), size * g, g, a.view(-1), g, c, p_, n_loc, g)
+        else:
+            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
+            pending = shard.all_gather_kv_async(k, v, shard_total)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+            yield i
+            k, v = pending.wait()
+            a = sa.attn(q, k, v)
+        # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
+        if own and own_gemm_ok(a.shape[1], c, c):      # the gated add happens in the GEMM's store
+            x = gemm_residual(x, a, sa.o.weight, sa.o.bias, mod, 2)
+            h = hip.ln_affine(x, blk.norm3.weight, blk.norm3.bias, eps)
+        else:
+            y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
+            if hot:
+                self._hot(f"blocks.{i}.self_attn.o", a, y)
+            x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+        return x, h
+
     # ------------------------------------------------------------------ the 30-block token forward
     def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None, tea_cache=None,
-                       skip_blocks=False):
+                       skip_blocks=False, cfg_prefix=None):
         """Run forward_tokens_steps to completion (single branch)."""
-        gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total, tea_cache, skip_blocks)
+        gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total, tea_cache, skip_blocks,
+                                        cfg_prefix)
         while True:
             try:
                 next(gen)
@@ -317,7 +379,7 @@ class WanModel(nn.Module):
                 return done.value
 
     def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None,
-                             tea_cache=None, skip_blocks=False):
+                             tea_cache=None, skip_blocks=False, cfg_prefix=None):
         """Generator form of the 30-block forward: yields right after each of a block's exchanges has been STARTED
         (token-sharded runs only: the K/V all-gather, or the two Ulysses all-to-alls), so a driver can interleave two
         independent forwards (the CFG branches) and let one branch's compute hide the other's xGMI traffic.
@@ -329,7 +391,13 @@ class WanModel(nn.Module):
         its attn_mode picks the exchange around self-attention (shard_total = N, all ranks' tokens).
         tea_cache / skip_blocks: the wan_video.TeaCache of this CFG branch and its verdict for this step — a skipped step
         re-applies the cached residual instead of running the 30 blocks, a computed one stores the new residual
-        (pipelines/wan_video.py:1297-1300,1316-1317,1375-1376)."""
+        (pipelines/wan_video.py:1297-1300,1316-1317,1375-1376).
+        cfg_prefix: a dict shared by the forwards of ONE denoise step that differ only in `context` (the CFG branches,
+        pipelines/wan_video.py:296-301).  Nothing before block 0's cross-attention sees the context, so the residual stream after
+        block 0's self-attention (norm1 + modulate, qkv, RMSNorm + RoPE, attention and its exchanges, o, gate) is the same tensor in
+        both: the first forward to get there leaves a copy, the other one takes it instead of computing it (bit-identical: the
+        kernels are deterministic).  A forward that arrives while the other is still inside that self-attention (lockstep
+        interleave) yields until the copy is there."""
         c, nh, eps = self.dim, self.num_heads, self.eps
         cos, sin = rope
         x = x.contiguous()
@@ -349,57 +417,22 @@ class WanModel(nn.Module):
             if fp8 is not None:
                 w8 = blk.fp8_weights(fp8)
                 lin = lambda t, j, bias, act=None: self._scaled_linear(*hip.fp8_quant_rows(t, act), w8[j], bias)      # noqa: E731
-            # --- self attention (reference :139-146)
             own = fp8 is None and not hot and mod.mod_rows in (1, 2)
-            if fp8 is not None:
-                qkv = lin(h, 0, bqkv)
-            elif GEMM_BACKEND == "all" and own and own_gemm_ok(h.shape[1], 3 * c, c):
-                qkv = gemm_bias_own(h, wqkv, bqkv)
-            else:
-                qkv = gemm_bias(h, wqkv, bqkv)
-            if hot:
-                for j, nm in enumerate(("q", "k", "v")):
-                    self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
-            v = qkv[..., 2 * c:]
-            if not sharded:
-                k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
-                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
-                a = sa.attn(q, k, v)
-            elif shard.attn_mode == "ulysses":
-                # token shard -> head shard (all N tokens of 24/P heads), attention, head shard -> token shard.  The
-                # norm+RoPE kernels and one strided copy write q | k | v straight into the all-to-all send buffer.
-                n_loc, p_, size = x.shape[1], shard.world_size, shard.chunk(shard_total)
-                g = c // nh * shard.heads_local(nh)
-                send = shard.ulysses_send_buffer(shard_total, c, qkv, n_loc)           # (P, chunk, 3, g)
-                flat, layout = send.view(-1), (g, size * 3 * g, 3 * g)
-                hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin, grouped=(flat, *layout))
-                hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin, grouped=(flat[g:], *layout))
-                hip.copy_groups(qkv.view(-1)[2 * c:], g, 3 * c, flat[2 * g:], size * 3 * g, 3 * g, p_, n_loc, g)
-                pending = shard.ulysses_exchange_async(send, shard_total)
-                yield i
-                qg, kg, vg = pending.wait()
-                o_full = shard.ulysses_out_buffer(shard_total, g, qkv)
-                hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0))
-                pending = shard.ulysses_out_async(o_full, shard_total, n_loc)
-                yield i
-                a = torch.empty((1, n_loc, c), dtype=qkv.dtype, device=qkv.device)
-                hip.copy_groups(pending.wait_blocks().view(-1), size * g, g, a.view(-1), g, c, p_, n_loc, g)
-            else:
-                k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
-                pending = shard.all_gather_kv_async(k, v, shard_total)
-                q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
-                yield i
-                k, v = pending.wait()
-                a = sa.attn(q, k, v)
-            # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
-            if own and own_gemm_ok(a.shape[1], c, c):      # the gated add happens in the GEMM's store
-                x = gemm_residual(x, a, sa.o.weight, sa.o.bias, mod, 2)
+            if cfg_prefix is not None and i == 0 and "owner" in cfg_prefix:
+                while "x_sa" not in cfg_prefix:      # the other branch is inside block 0's self-attention: let it run
+                    yield i
+                x = cfg_prefix.pop("x_sa")
                 h = hip.ln_affine(x, blk.norm3.weight, blk.norm3.bias, eps)
+                reuse = True
             else:
-                y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
-                if hot:
-                    self._hot(f"blocks.{i}.self_attn.o", a, y)
-                x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+                reuse = False
+                if cfg_prefix is not None and i == 0:
+                    cfg_prefix["owner"] = True
+            # --- self attention (reference :139-146)
+            if not reuse:
+                x, h = yield from self._self_attention_steps(i, blk, mod, x, h, cos, sin, shard, shard_total, own, lin if fp8 is not None else None)
+                if cfg_prefix is not None and i == 0:
+                    cfg_prefix["x_sa"] = x.clone()
             # --- cross attention (reference :170-185)
             if fp8 is None:
                 qc = gemm_bias_own(h, ca.q.weight, ca.q.bias) if own and own_gemm_ok(h.shape[1], c, c) else gemm_bias(h, ca.q.weight, ca.q.bias)

@@ -57,7 +57,8 @@ def test_tiny_dit_forward_vs_golden(tiny_dit, golden):
         assert (out.float().cpu() - g[key].float()).abs().max().item() < 0.08
 
 
-def test_tiny_denoise_loop_vs_golden(tiny_dit, golden):
+def test_tiny_denoise_loop_vs_golden(tiny_dit, golden, monkeypatch):
+    from fairygen_amd import wan_video
     from fairygen_amd.wan_video import WanVideoPipeline
     g = golden("dit_tiny.safetensors")
     m, sd, cfg = tiny_dit
@@ -73,6 +74,14 @@ def test_tiny_denoise_loop_vs_golden(tiny_dit, golden):
     want = g["loop_step3"]
     assert cos(out, want) > 0.999
     assert torch.equal(out[:, :, 0:1].cpu(), z0)
+    # the loop above shared block 0's self-attention between the two CFG forwards of a step (cfg_prefix: they differ only in the
+    # context); computing it in both, as the reference does, gives the same latents bit for bit
+    assert wan_video.CFG_SHARE_PREFIX
+    monkeypatch.setattr(wan_video, "CFG_SHARE_PREFIX", False)
+    shared = {"latents": latents.cuda(), "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0.cuda()}
+    with torch.no_grad():
+        out2 = pipe.denoise(shared, {"context": ctx_p.cuda()}, {"context": ctx_n.cuda()}, 5.0, progress_bar_cmd=lambda x: x)
+    assert torch.equal(out, out2)
 
 
 def test_teacache_loop_vs_golden(tiny_dit, golden):
