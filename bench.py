@@ -421,6 +421,10 @@ def main():
             "roofline": roofline,
         }
         line["config"]["gelu"] = "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel"
+        from fairygen_amd import wan_video as _wv, wan_video_dit as _wd
+        line["config"]["dit_gemm_backend"] = _wd.GEMM_BACKEND + " (FAIRYGEN_GEMM: which Linears run on gemm_p_kernel instead of hipBLASLt)"
+        line["config"]["cfg_shared_prefix"] = ("block 0's self-attention computed once per step for both CFG forwards (identical inputs, bit-identical "
+                                               "result; FAIRYGEN_CFG_SHARE=0 computes it twice)") if _wv.CFG_SHARE_PREFIX else "off"
         if args.sliding_window:
             line["config"]["APPROXIMATE_sliding_window"] = args.sliding_window + " (reference TemporalTiler mode, not the default path)"
         if autotune is not None:
