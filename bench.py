@@ -425,6 +425,8 @@ def main():
         line["config"]["dit_gemm_backend"] = _wd.GEMM_BACKEND + " (FAIRYGEN_GEMM: which Linears run on gemm_p_kernel instead of hipBLASLt)"
         line["config"]["cfg_shared_prefix"] = ("block 0's self-attention computed once per step for both CFG forwards (identical inputs, bit-identical "
                                                "result; FAIRYGEN_CFG_SHARE=0 computes it twice)") if _wv.CFG_SHARE_PREFIX else "off"
+        line["config"]["cross_attention_kv"] = ("computed at the first step, kept for the loop (prompt and weights are constant; bit-identical; "
+                                                "FAIRYGEN_CROSS_KV_CACHE=0 recomputes per step)") if _wv.CROSS_KV_CACHE else "recomputed per step"
         if args.sliding_window:
             line["config"]["APPROXIMATE_sliding_window"] = args.sliding_window + " (reference TemporalTiler mode, not the default path)"
         if autotune is not None:

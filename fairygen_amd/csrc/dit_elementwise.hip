@@ -5,6 +5,13 @@
 // Rounding points mirror the reference's bf16 tensor arithmetic op by op (see include/fairygen_hip.h).
 #include "common.h"
 
+// Row kernels (one wave per token row held in registers): second launch-bound = minimum waves per SIMD the register
+// allocation must allow (FG_ROW_MIN_WAVES; measured in tools/microbench.py elementwise).
+#ifndef FG_ROW_MIN_WAVES
+#define FG_ROW_MIN_WAVES 4
+#endif
+#define FG_ROW_BOUNDS __launch_bounds__(256, FG_ROW_MIN_WAVES)
+
 namespace {
 
 constexpr int kMaxVec = 8;            // 8 lanes-vectors * 64 lanes * 8 elems = 4096 channels max
@@ -96,7 +103,7 @@ __device__ __forceinline__ void norm_store(const Row& r, int C, int lane, float 
     }
 }
 
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shift,
+__global__ FG_ROW_BOUNDS void ln_modulate_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shift,
                                                           const bf16* __restrict__ scale, bf16* __restrict__ out,
                                                           int64_t rows, int C, float eps, int64_t mod_rows,
                                                           int64_t first_rows, int64_t mod_ld) {
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict
     norm_store<0>(r, C, lane, eps, shift + m * mod_ld, scale + m * mod_ld, out + row * C);
 }
 
-__global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+__global__ FG_ROW_BOUNDS void ln_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                         const bf16* __restrict__ b, bf16* __restrict__ out,
                                                         int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
 
 // x_out = x + gate*y ; optional fused norm of x_out.  MODE: -1 none, 0 modulate, 1 affine.
 template <int MODE>
-__global__ __launch_bounds__(256) void residual_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y,
+__global__ FG_ROW_BOUNDS void residual_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y,
                                                        const bf16* __restrict__ gate, bf16* __restrict__ x_out,
                                                        const bf16* __restrict__ p0, const bf16* __restrict__ p1,
                                                        bf16* __restrict__ norm_out, int64_t rows, int C, float eps,
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void residual_kernel(const bf16* __restrict__ 
 // the fp64 table rounded once, rotation as two fp32 FMAs: the bf16 result differs from the fp64 one only where the
 // exact value lies within ~2e-7 relative of a bf16 rounding boundary (measured in tests/test_hip_kernels.py).
 template <bool F32TAB>
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
+__global__ FG_ROW_BOUNDS void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
                                                            const bf16* __restrict__ w, const void* __restrict__ ctv,
                                                            const void* __restrict__ stv, bf16* __restrict__ out,
                                                            int64_t rows, int C, int head_dim, float eps, int group_cols,

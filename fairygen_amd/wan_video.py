@@ -514,6 +514,8 @@ class WanVideoPipeline(torch.nn.Module):
         share = (CFG_SHARE_PREFIX and cfg_scale != 1.0 and self.model_fn is model_fn_wan_video and not cfg_split and not cfg_merge
                  and inputs_posi.get("tea_cache") is None and inputs_nega.get("tea_cache") is None
                  and shared.get("sliding_window_size") is None)
+        if CROSS_KV_CACHE and self.model_fn is model_fn_wan_video and shared.get("sliding_window_size") is None:
+            shared["kv_cache"] = {}      # lives for this loop only: the prompt embeddings and the weights do not change inside it
         for progress_id, timestep in enumerate(progress_bar_cmd(self.scheduler.timesteps)):
             ts = timestep.unsqueeze(0).to(dtype=self.torch_dtype)       # bf16 rounding of t (:293), kept on the host
             shared["latents"] = latents
@@ -550,6 +552,7 @@ class WanVideoPipeline(torch.nn.Module):
 
 
 CFG_SHARE_PREFIX = os.environ.get("FAIRYGEN_CFG_SHARE", "1") != "0"
+CROSS_KV_CACHE = os.environ.get("FAIRYGEN_CROSS_KV_CACHE", "1") != "0"
 
 
 def inputs_posi_ctx(d):
@@ -644,7 +647,7 @@ def temporal_tiler_steps(window_fn, latents, sliding_window_size, sliding_window
 
 def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fuse_vae_embedding_in_latents=False,
                              sequence_shard=None, gather_output=True, tea_cache=None, sliding_window_size=None,
-                             sliding_window_stride=None, cfg_prefix=None, **kwargs):
+                             sliding_window_stride=None, cfg_prefix=None, kv_cache=None, **kwargs):
     """Generator form of the forward (yields where WanModel.forward_tokens_steps yields; returns the prediction, or
     with gather_output=False the head output of this rank's tokens (1, n_local, out_dim*prod(patch)) and the grid).
 
@@ -665,7 +668,8 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
             outs.append((yield from model_fn_wan_video_steps(
                 dit, latents=latents, timestep=timestep, context=context[b:b + 1], sequence_shard=sequence_shard,
                 fuse_vae_embedding_in_latents=fuse_vae_embedding_in_latents, gather_output=gather_output,
-                sliding_window_size=sliding_window_size, sliding_window_stride=sliding_window_stride, cfg_prefix=prefix)))
+                sliding_window_size=sliding_window_size, sliding_window_stride=sliding_window_stride, cfg_prefix=prefix,
+                kv_cache=kv_cache)))
         if not gather_output:
             return torch.cat([o[0] for o in outs], dim=0), outs[0][1]
         return torch.cat(outs, dim=0)
@@ -695,8 +699,18 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     proj = dit.time_projection[1]
     mod_rows_t = F.linear(hip.activation(t_rows.clone(), "silu"), proj.weight, proj.bias).unflatten(1, (6, dit.dim))
 
-    tx = dit.text_embedding
-    ctx = F.linear(hip.activation(F.linear(context, tx[0].weight, tx[0].bias), "gelu_tanh"), tx[2].weight, tx[2].bias)
+    # what depends on the prompt embedding and the weights only — the text_embedding MLP here, the cross-attention K / V of every
+    # block in forward_tokens_steps — is kept for the denoise loop that owns kv_cache (keyed by the prompt tensor)
+    kv = None
+    if kv_cache is not None and sliding_window_size is None:
+        kv = kv_cache.setdefault((context.data_ptr(), tuple(context.shape), context._version), {})
+    if kv is not None and "ctx" in kv:
+        ctx = kv["ctx"]
+    else:
+        tx = dit.text_embedding
+        ctx = F.linear(hip.activation(F.linear(context, tx[0].weight, tx[0].bias), "gelu_tanh"), tx[2].weight, tx[2].bias)
+        if kv is not None:
+            kv["ctx"] = ctx
 
     x, (f, h, w) = dit.patchify(latents)
     n = f * h * w
@@ -708,14 +722,14 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         skip = tea_cache is not None and tea_cache.check(dit, x_loc, TimeModulation(mod_rows_t, first_rows, n))
         out_loc = yield from dit.forward_tokens_steps(x_loc, ctx, mod_rows_t, t_rows, min(max(first_rows - lo, 0), hi - lo),
                                                       (cos[lo:hi].contiguous(), sin[lo:hi].contiguous() if sin is not None else None), sequence_shard, n,
-                                                      tea_cache, skip, cfg_prefix if tea_cache is None else None)
+                                                      tea_cache, skip, cfg_prefix if tea_cache is None else None, kv)
         if not gather_output:
             return out_loc, (f, h, w)
         out = sequence_shard.all_gather_tokens(out_loc, n)
     else:
         skip = tea_cache is not None and tea_cache.check(dit, x, TimeModulation(mod_rows_t, first_rows, n))
         out = yield from dit.forward_tokens_steps(x, ctx, mod_rows_t, t_rows, first_rows, (cos, sin), None, None, tea_cache, skip,
-                                                  cfg_prefix if tea_cache is None else None)
+                                                  cfg_prefix if tea_cache is None else None, kv)
         if not gather_output:
             return out, (f, h, w)
     return dit.unpatchify(out, (f, h, w))

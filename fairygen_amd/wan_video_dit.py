@@ -368,10 +368,10 @@ class WanModel(nn.Module):
 
     # ------------------------------------------------------------------ the 30-block token forward
     def forward_tokens(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None, tea_cache=None,
-                       skip_blocks=False, cfg_prefix=None):
+                       skip_blocks=False, cfg_prefix=None, kv_cache=None):
         """Run forward_tokens_steps to completion (single branch)."""
         gen = self.forward_tokens_steps(x, context, mod_rows_t, t_rows, first_rows, rope, shard, shard_total, tea_cache, skip_blocks,
-                                        cfg_prefix)
+                                        cfg_prefix, kv_cache)
         while True:
             try:
                 next(gen)
@@ -379,7 +379,7 @@ class WanModel(nn.Module):
                 return done.value
 
     def forward_tokens_steps(self, x, context, mod_rows_t, t_rows, first_rows, rope, shard=None, shard_total=None,
-                             tea_cache=None, skip_blocks=False, cfg_prefix=None):
+                             tea_cache=None, skip_blocks=False, cfg_prefix=None, kv_cache=None):
         """Generator form of the 30-block forward: yields right after each of a block's exchanges has been STARTED
         (token-sharded runs only: the K/V all-gather, or the two Ulysses all-to-alls), so a driver can interleave two
         independent forwards (the CFG branches) and let one branch's compute hide the other's xGMI traffic.
@@ -397,7 +397,10 @@ class WanModel(nn.Module):
         block 0's self-attention (norm1 + modulate, qkv, RMSNorm + RoPE, attention and its exchanges, o, gate) is the same tensor in
         both: the first forward to get there leaves a copy, the other one takes it instead of computing it (bit-identical: the
         kernels are deterministic).  A forward that arrives while the other is still inside that self-attention (lockstep
-        interleave) yields until the copy is there."""
+        interleave) yields until the copy is there.
+        kv_cache: a dict that lives as long as `context` and the weights stay what they are (one denoise loop): block i's
+        cross-attention keys (after norm_k) and values depend on nothing else, so they are computed at the first step and read
+        back at the others (reference :172-177 recomputes them every step)."""
         c, nh, eps = self.dim, self.num_heads, self.eps
         cos, sin = rope
         x = x.contiguous()
@@ -436,17 +439,22 @@ class WanModel(nn.Module):
             # --- cross attention (reference :170-185)
             if fp8 is None:
                 qc = gemm_bias_own(h, ca.q.weight, ca.q.bias) if own and own_gemm_ok(h.shape[1], c, c) else gemm_bias(h, ca.q.weight, ca.q.bias)
-                kvc = gemm_bias(context, wkv_c, bkv_c)
             else:
                 qc = lin(h, 2, ca.q.bias)
-                kvc = self._scaled_linear(*ctx8, w8[3], bkv_c)
             if hot:
                 self._hot(f"blocks.{i}.cross_attn.q", h, qc)
-                self._hot(f"blocks.{i}.cross_attn.k", context, kvc[..., :c])
-                self._hot(f"blocks.{i}.cross_attn.v", context, kvc[..., c:])
             qc = hip.rmsnorm_rope(qc, ca.norm_q.weight, nh, eps)
-            kc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps)
-            ac = ca.attn(qc, kc, kvc[..., c:])
+            if kv_cache is not None and i in kv_cache:
+                kc, vc = kv_cache[i]
+            else:
+                kvc = gemm_bias(context, wkv_c, bkv_c) if fp8 is None else self._scaled_linear(*ctx8, w8[3], bkv_c)
+                if hot:
+                    self._hot(f"blocks.{i}.cross_attn.k", context, kvc[..., :c])
+                    self._hot(f"blocks.{i}.cross_attn.v", context, kvc[..., c:])
+                kc, vc = hip.rmsnorm_rope(kvc[..., :c], ca.norm_k.weight, nh, eps), kvc[..., c:]
+                if kv_cache is not None:
+                    kv_cache[i] = (kc, vc)
+            ac = ca.attn(qc, kc, vc)
             # x += y ; h = modulate(norm2(x))  (reference :226-227)
             if own and own_gemm_ok(ac.shape[1], c, c):
                 x = gemm_residual(x, ac, ca.o.weight, ca.o.bias)

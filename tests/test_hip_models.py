@@ -75,9 +75,11 @@ def test_tiny_denoise_loop_vs_golden(tiny_dit, golden, monkeypatch):
     assert cos(out, want) > 0.999
     assert torch.equal(out[:, :, 0:1].cpu(), z0)
     # the loop above shared block 0's self-attention between the two CFG forwards of a step (cfg_prefix: they differ only in the
-    # context); computing it in both, as the reference does, gives the same latents bit for bit
-    assert wan_video.CFG_SHARE_PREFIX
+    # context) and computed the cross-attention K / V of every block once for all steps (kv_cache: they depend on the prompt and
+    # the weights only); computing everything in every forward, as the reference does, gives the same latents bit for bit
+    assert wan_video.CFG_SHARE_PREFIX and wan_video.CROSS_KV_CACHE
     monkeypatch.setattr(wan_video, "CFG_SHARE_PREFIX", False)
+    monkeypatch.setattr(wan_video, "CROSS_KV_CACHE", False)
     shared = {"latents": latents.cuda(), "fuse_vae_embedding_in_latents": True, "first_frame_latents": z0.cuda()}
     with torch.no_grad():
         out2 = pipe.denoise(shared, {"context": ctx_p.cuda()}, {"context": ctx_n.cuda()}, 5.0, progress_bar_cmd=lambda x: x)
