@@ -23,7 +23,7 @@ TAB = 131072                           # tile records (48 B each) above the two 
 SB = 36                                # s32..s34 are reserved by the compiler (stack / frame / base pointer)
 S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, GD=16, WAVE=20, NK=21, LDA=22, LDC=23, KOFF=24, T=25, TI=26, TMP0=27,
                                 TMP1=28, TMP2=29, WDST=30, XDST=31, KW=32, FLAGS=33, FIRST=34, GLD=35, TMP64=36, ST1=38,
-                                GBASE=40, M0ROW=42, REC=44).items()}      # REC: 16 SGPRs of the current tile record
+                                GBASE=40, M0ROW=42, KIND=43, REC=44).items()}      # REC: 16 SGPRs of the current tile record
 NSREG = 62                             # ... and the L2-prefetch lane shifts (s96, s97)
 PF_SX, PF_SW = SB + 60, SB + 61
 F0, F1 = 0, 32
@@ -79,8 +79,9 @@ def acc(ni, mi, j=0):
 
 def emit_setup(E, C, first=True):
     """%0 kernarg-independent scalars: %0 wave, %1 K/64, %2 lda bytes, %3 ldc bytes, %4 K bytes, %5 flags, %6 first_rows (gate class)."""
-    for n, name in enumerate(["WAVE", "NK", "LDA", "LDC", "KW", "FLAGS", "FIRST"]):
-        E.e(f"s_mov_b32 {sr(S[name])}, %{n}")
+    for n, name in enumerate(["WAVE", None, "LDA", "LDC", "KW", "FLAGS", "FIRST"]):      # %1 (K/64) is in every tile record now
+        if name:
+            E.e(f"s_mov_b32 {sr(S[name])}, %{n}")
     for base in (S["XD"], S["WD"], S["CD"], S["BD"], S["GD"]):
         E.e(f"s_mov_b32 {sr(base + 3)}, 0x00020000")
     E.e(f"s_mul_i32 {sr(S['WDST'])}, {sr(S['WAVE'])}, {C.npw * 1024}")
@@ -206,13 +207,17 @@ def emit_load_record(E, part):
         E.e(f"s_mov_b64 {sr(S['WD'], 2)}, {sr(S['REC'] + 2, 2)}")
         E.e(f"s_mov_b32 {sr(S['WD'] + 2)}, {sr(S['REC'] + 13)}")
         # cooperative L2 prefetch: this CU pulls activation rows l % 8 == record[14] and weight rows l % 4 == record[15]
-        E.e(f"s_mov_b32 {sr(PF_SX)}, {sr(S['REC'] + 14)}")
-        E.e(f"s_mov_b32 {sr(PF_SW)}, {sr(S['REC'] + 15)}")
+        E.e(f"s_and_b32 {sr(PF_SX)}, {sr(S['REC'] + 14)}, 0xff")
+        E.e(f"s_lshr_b32 {sr(PF_SW)}, {sr(S['REC'] + 14)}, 8")
+        # the tile's k range: record[15] = first byte of the range in a row | k-steps << 16 (a whole tile: 0 | K/64 << 16; a piece
+        # of a k-split tile of the last round: its part, the fp32 accumulators then go to the workspace: KIND 2)
+        E.e(f"s_lshr_b32 {sr(S['NK'])}, {sr(S['REC'] + 15)}, 16")
     else:
         E.e(f"s_mov_b64 {sr(S['CD'], 2)}, {sr(S['REC'] + 4, 2)}")
         E.e(f"s_mov_b32 {sr(S['CD'] + 2)}, {sr(S['REC'] + 9)}")
         E.e(f"s_mov_b64 {sr(S['BD'], 2)}, {sr(S['REC'] + 6, 2)}")
         E.e(f"s_mov_b32 {sr(S['M0ROW'])}, {sr(S['REC'] + 11)}")            # m0 of the tile (token class of a row: m0 + row < FIRST)
+        E.e(f"s_mov_b32 {sr(S['KIND'])}, {sr(S['REC'] + 10)}")
         E.e(f"s_add_u32 {sr(S['GD'])}, {sr(S['GBASE'])}, {sr(S['REC'] + 12)}")     # gate vector at the tile's first column
         E.e(f"s_addc_u32 {sr(S['GD'] + 1)}, {sr(S['GBASE'] + 1)}, 0")
 
@@ -347,8 +352,10 @@ def n_dma_k0(C):
 def emit_dma_k0(E, C):
     """The tile's first k-slice -> stage 0 (ring of 3: and the second -> stage 1), and the L2 prefetch of the slices the first
     pf_dist steps will fetch."""
+    E.e(f"s_and_b32 {sr(S['KOFF'])}, {sr(S['REC'] + 15)}, 0xffff")
     for sl in range(C.ring - 1):
-        E.e(f"s_mov_b32 {sr(S['KOFF'])}, {128 * sl}")
+        if sl:
+            E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
         for op, n in (("W", C.npw), ("X", 8)):
             for i in range(n):
                 for ln in dma_piece(C, op, i, sl):
@@ -357,7 +364,7 @@ def emit_dma_k0(E, C):
         for op in pf_ops(C):
             for ln in prefetch_lines(C, op, d):
                 E.e(ln)
-    E.e(f"s_mov_b32 {sr(S['KOFF'])}, {128 * (C.ring - 1)}")
+    E.e(f"s_add_u32 {sr(S['KOFF'])}, {sr(S['KOFF'])}, 128")
 
 
 def qoff(q):
@@ -422,7 +429,9 @@ def emit_epilogue(E, C, n_dma):
         E.e(f"buffer_store_dwordx4 {vr(V_YR + 4 * it, 4)}, {vr(V_SOFF)}, {sr(S['CD'], 4)}, {sr(S['TMP0'])} offen")
         E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {sr(S['TMP2'])}")
 
-    plain, resid, done = E.label("epiplain"), E.label("epiresid"), E.label("epidone")
+    plain, resid, done, raw = E.label("epiplain"), E.label("epiresid"), E.label("epidone"), E.label("epiraw")
+    E.e(f"s_cmp_eq_u32 {sr(S['KIND'])}, 2")
+    E.e(f"s_cbranch_scc1 {raw}")
     E.e(f"s_cmp_lt_u32 {sr(S['FLAGS'])}, 2")
     E.e(f"s_cbranch_scc1 {plain}")
     E.e(f"s_cmp_eq_u32 {sr(S['FLAGS'])}, 3")
@@ -477,6 +486,26 @@ def emit_epilogue(E, C, n_dma):
         for it in range(8):
             store(it)
     E.e("s_waitcnt vmcnt(32)")                       # the LDS-DMA of the next tile's first k-slice has landed (no stall this late)
+    E.e(f"s_branch {done}")
+    # ---- a k-range piece: the fp32 accumulators as they stand -> the piece's workspace slot (CD), straight from the AGPRs.
+    # Layout: dwordx4 number s = (ni*4 + mi)*4 + g of a wave at byte ((wave*(NB*16) + s)*64 + lane)*16: fg_gemm_reduce_kernel
+    # (dit_gemm.hip) adds the pieces of a tile in k order and applies the epilogue.
+    E.e(f"{raw}:")
+    E.e(f"v_mbcnt_lo_u32_b32 {vr(TB)}, -1, 0")
+    E.e(f"v_mbcnt_hi_u32_b32 {vr(TB)}, -1, {vr(TB)}")
+    E.e(f"v_lshlrev_b32 {vr(TB)}, 4, {vr(TB)}")
+    E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, {nq * 4 * 1024}")
+    n = 0
+    for ni in range(C.nb):
+        for mi in range(4):
+            for g in range(4):
+                E.e(f"buffer_store_dwordx4 {ar(acc(ni, mi, 4 * g), 4)}, {vr(TB)}, {sr(S['CD'], 4)}, {sr(S['TMP0'])} offen")
+                E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, 1024")
+                n += 1
+                if n == 32:
+                    E.e("s_waitcnt vmcnt(32)")          # the next tile's LDS-DMA (older than these stores) has landed
+    if n < 32:
+        E.e(f"s_waitcnt vmcnt({n})")
     E.e(f"{done}:")
 
 

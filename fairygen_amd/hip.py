@@ -29,7 +29,7 @@ _SIGNATURES = {
     "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
     "fg_gemm_bias_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
-    "fg_gemm_epilogue_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _vp],
+    "fg_gemm_epilogue_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _vp, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
@@ -49,7 +49,7 @@ _SIGNATURES = {
     "fg_gated_gelu_bf16": [_vp, _vp, _vp, _i64, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice",
-                                                   "fg_conv_tile_choice"])
+                                                   "fg_conv_tile_choice", "fg_gemm_workspace_bytes"])
 
 
 class HipLibraryError(RuntimeError):
@@ -78,6 +78,8 @@ def load():
     lib.fg_attn_workspace_bytes.argtypes = [_i32, _i64, _i64, _i32]
     lib.fg_conv_tile_choice.restype = ctypes.c_int
     lib.fg_conv_tile_choice.argtypes = [_i32] * 4
+    lib.fg_gemm_workspace_bytes.restype = ctypes.c_int64
+    lib.fg_gemm_workspace_bytes.argtypes = [_i64] * 3
     lib.fg_attn_split_choice.restype = ctypes.c_int
     lib.fg_attn_split_choice.argtypes = [_i32, _i64, _i64, _i32, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     for name, argtypes in _SIGNATURES.items():
@@ -280,10 +282,14 @@ def gemm_bias(x, weight, bias, out=None):
     return out
 
 
-def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=None):
+_gemm_workspace = {}      # (device, stream) -> scratch for the k-split pieces of a GEMM's last round (64 MiB, reused)
+
+
+def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=None, workspace=True):
     """Linear on the persistent MFMA kernel.  residual=False: out = x @ weight^T + bias.  residual=True: `out` holds the residual
     stream and becomes out + gate * (x @ weight^T + bias) (gate = vector gate_idx of `mod`, or 1 when mod is None), with the
-    reference's rounding points (GateModule, models/wan_video_dit.py:188-193)."""
+    reference's rounding points (GateModule, models/wan_video_dit.py:188-193).  workspace=False: no k-split of the last round's tiles
+    (every element one k-ordered accumulation, independent of the row count)."""
     _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
     k = x.shape[-1]
     n = weight.shape[0]
@@ -299,14 +305,21 @@ def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=
         _dev(out, "out")
     else:
         out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
+    ws = None
+    need = load().fg_gemm_workspace_bytes(m, n, k) if workspace else 0
+    if need > 0:
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)      # concurrent streams must not share scratch
+        ws = _gemm_workspace.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _gemm_workspace[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
     if residual and mod is not None:
         if mod.mod_rows not in (1, 2) or mod.c != n:
             raise HipLibraryError("gemm_epilogue: the gate table must have 1 or 2 rows of N values")
         _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 2, mod.vec(gate_idx),
-              mod.mod_rows, mod.ld, mod.first_rows, _stream(x))
+              mod.mod_rows, mod.ld, mod.first_rows, _ptr(ws) if ws is not None else None, _stream(x))
     else:
         _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 3 if residual else 0, None,
-              1, n, 0, _stream(x))
+              1, n, 0, _ptr(ws) if ws is not None else None, _stream(x))
     return out
 
 

@@ -55,11 +55,13 @@ def gemm_bias_tuned(x, weight, bias):
 
 
 # The DiT Linears that run on this repo's own persistent MFMA kernel (fg_gemm_epilogue_bf16, csrc/gen_gemm_p.py) — also seams for
-# bench.py.  FAIRYGEN_GEMM = "fused" (default): the 3072 x 3072 projections — self-attention o and cross-attention o, whose output
-# goes straight into the residual stream (the GateModule add happens in the GEMM's store, so the following LayerNorm reads x once
-# instead of x and y), and the cross-attention q; "fused+ffn2": ffn.2 with gate_mlp too (measured at parity with the library +
-# residual kernel: K = 14336 makes the left-over 64-column pieces of the last round expensive); "all": qkv as well; "lib":
-# everything on hipBLASLt.
+# bench.py.  FAIRYGEN_GEMM = "fused" (default): the 3072 x 3072 projections — self-attention o (gate_msa) and cross-attention o, whose
+# output goes straight into the residual stream (the GateModule add happens in the GEMM's store, so the following LayerNorm reads
+# x once instead of x and y), and the cross-attention q; "fused+ffn2": ffn.2 (gate_mlp) too; "all": qkv as well; "lib": everything
+# on hipBLASLt.  ffn.0 stays on the library in every mode (GELU in its epilogue).  Measured in the 704x1280x121 denoise step, same
+# box: lib 790.9, fused 787.2, fused+ffn2 790.1, all 791.3 ms — kernel for kernel the own GEMM is at or above the library's rate
+# (tools/gemm_ab.py), but the step is power-bound: what the own kernel gains on ffn.2 the library's qkv / ffn.0 lose in clock, so
+# only the removed elementwise traffic shows up.
 GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "fused")
 
 

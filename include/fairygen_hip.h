@@ -84,11 +84,15 @@ int fg_gemm_bias_bf16(const void* a, int64_t lda, const void* w, const void* bia
  * with the bf16 rounding points of the reference's three separate ops.  gate: a table of gate_rows (1 or 2) rows of N values, row
  * stride gate_ld elements; with 2 rows, output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the
  * others row 1.  N %% 256 == 0 or N %% 192 == 0, K %% 128 == 0.  Persistent kernel: one workgroup per CU walks a list of
- * 256 x 256 or 256 x 192 output tiles (csrc/gen_gemm_p.py); the tile width is picked per shape so that the tile count fills
- * whole rounds of the 256 CUs.  Every output element is one full-K fp32 accumulation in k order, whatever the tiling. */
+ * 256 x 256 (N %% 256 == 0) or 256 x 192 output tiles (csrc/gen_gemm_p.py).  The tiles left over after the last whole round of the
+ * 256 CUs are finished as pieces: with `workspace` (fg_gemm_workspace_bytes(M, N, K) bytes of device memory, 16-byte aligned; may
+ * be NULL) cut along K into fp32 partial sums that a second small kernel adds in k order before the same epilogue — those
+ * elements' fp32 summation is then grouped per piece (fixed for a given shape; every other element is one full-K accumulation in
+ * k order); without it, cut into 64-column pieces, every element accumulated in k order. */
+int64_t fg_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int fg_gemm_epilogue_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
-                          int64_t first_rows, fg_stream_t stream);
+                          int64_t first_rows, void* workspace, fg_stream_t stream);
 
 /* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
  * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,

@@ -112,9 +112,10 @@ def main():
         if stamp_p is not None:
             import numpy as np
             o2 = torch.zeros_like(ref)
+            wsp = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             for _ in range(3):
-                stamp_p.fg_gemm_epilogue_bf16(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), o2.data_ptr(), n, a.m, n, k, 0, None, 1, n, 0, st)
+                stamp_p.fg_gemm_epilogue_bf16(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), o2.data_ptr(), n, a.m, n, k, 0, None, 1, n, 0, wsp.data_ptr(), st)
             buf = np.zeros((256, 4, 8), dtype=np.uint32)
             stamp_p.fg_gemm_stamp_read(buf.ctypes.data_as(ctypes.c_void_p), st)
             w0 = buf[:, 0, :].astype(np.float64)          # wave 0 of every workgroup: kloop, epilogue, wait, tiles, total, ticks
