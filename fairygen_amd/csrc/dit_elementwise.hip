@@ -103,6 +103,72 @@ __device__ __forceinline__ void norm_store(const Row& r, int C, int lane, float 
     }
 }
 
+// Two fp32 -> two e4m3 bytes in the low half of a dword (v_cvt_pk_fp8_f32: RNE, OCP e4m3fn on gfx950).
+__device__ __forceinline__ uint32_t cvt2_fp8(float a, float b) {
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
+// The same normalised row as norm_store, but handed to the fp8 Linear that consumes it (AutoWrappedLinear.fp8_linear,
+// core/vram/layers.py:331-342) without a trip through HBM: the bf16-rounded values stay in registers, the row maximum gives the
+// dynamic scale, the row leaves as e4m3 bytes + one fp32 scale — exactly fg_fp8_quant_rows_bf16's arithmetic on norm_store's output.
+template <int MODE>
+__device__ __forceinline__ void norm_store_fp8(Row& r, int C, int lane, float eps, const bf16* p0, const bf16* p1,
+                                               uint8_t* out8, float* scale_out, float fp8_max) {
+    const int nvec = C >> 3;
+    float mean, rstd;
+    row_moments(r, C, lane, eps, mean, rstd);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const bf16x8 a = ld8(p0 + (int64_t)vi * 8);
+            const bf16x8 b = ld8(p1 + (int64_t)vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = (r.v[i][j] - mean) * rstd;
+                float o;
+                if (MODE == 0) {
+                    const float y = rbf(n);
+                    const float s1 = rbf(1.0f + (float)b[j]);
+                    o = rbf(y * s1) + (float)a[j];
+                } else {
+                    o = n * (float)a[j] + (float)b[j];
+                }
+                r.v[i][j] = rbf(o);
+                amax = fmaxf(amax, fabsf(r.v[i][j]));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = fmaxf(rbf(amax / fp8_max), 1.0f);
+    const float denom = sc + 1e-8f;
+    if (lane == 0) *scale_out = sc;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            u32x2 w;
+            w[0] = cvt2_fp8(r.v[i][0] / denom, r.v[i][1] / denom) | (cvt2_fp8(r.v[i][2] / denom, r.v[i][3] / denom) << 16);
+            w[1] = cvt2_fp8(r.v[i][4] / denom, r.v[i][5] / denom) | (cvt2_fp8(r.v[i][6] / denom, r.v[i][7] / denom) << 16);
+            *reinterpret_cast<u32x2*>(out8 + (int64_t)vi * 8) = w;
+        }
+    }
+}
+
+__global__ FG_ROW_BOUNDS void ln_modulate_fp8_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shift,
+                                                     const bf16* __restrict__ scale, uint8_t* __restrict__ out8,
+                                                     float* __restrict__ scale_out, int64_t rows, int C, float eps, int64_t mod_rows,
+                                                     int64_t first_rows, int64_t mod_ld, float fp8_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row r;
+    load_row(x + row * C, C, lane, r);
+    const int64_t m = mod_row(row, mod_rows, first_rows);
+    norm_store_fp8<0>(r, C, lane, eps, shift + m * mod_ld, scale + m * mod_ld, out8 + row * C, scale_out + row, fp8_max);
+}
+
 __global__ FG_ROW_BOUNDS void ln_modulate_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shift,
                                                           const bf16* __restrict__ scale, bf16* __restrict__ out,
                                                           int64_t rows, int C, float eps, int64_t mod_rows,
@@ -133,7 +199,9 @@ __global__ FG_ROW_BOUNDS void residual_kernel(const bf16* __restrict__ x, const 
                                                        const bf16* __restrict__ gate, bf16* __restrict__ x_out,
                                                        const bf16* __restrict__ p0, const bf16* __restrict__ p1,
                                                        bf16* __restrict__ norm_out, int64_t rows, int C, float eps,
-                                                       int64_t mod_rows, int64_t first_rows, int64_t mod_ld) {
+                                                       int64_t mod_rows, int64_t first_rows, int64_t mod_ld,
+                                                       uint8_t* __restrict__ norm_fp8 = nullptr, float* __restrict__ norm_scale = nullptr,
+                                                       float fp8_max = 0.f) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -159,6 +227,11 @@ __global__ FG_ROW_BOUNDS void residual_kernel(const bf16* __restrict__ x, const 
 #pragma unroll
             for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
         }
+    }
+    if (norm_fp8 != nullptr) {      // the norm feeds an fp8 Linear only: e4m3 row + scale instead of the bf16 row
+        if (MODE == 0) norm_store_fp8<0>(r, C, lane, eps, p0 + m * mod_ld, p1 + m * mod_ld, norm_fp8 + row * C, norm_scale + row, fp8_max);
+        if (MODE == 1) norm_store_fp8<1>(r, C, lane, eps, p0, p1, norm_fp8 + row * C, norm_scale + row, fp8_max);
+        return;
     }
     if (MODE == 0) norm_store<0>(r, C, lane, eps, p0 + m * mod_ld, p1 + m * mod_ld, norm_out + row * C);
     if (MODE == 1) norm_store<1>(r, C, lane, eps, p0, p1, norm_out + row * C);
@@ -308,6 +381,42 @@ int fg_ln_modulate_bf16(const void* x, const void* shift, const void* scale, voi
     hipLaunchKernelGGL(ln_modulate_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                        (const bf16*)shift, (const bf16*)scale, (bf16*)out, rows, C, eps, mod_rows, first_rows, mod_ld);
     return fg_launch_status("fg_ln_modulate_bf16");
+}
+
+int fg_ln_modulate_fp8_bf16(const void* x, const void* shift, const void* scale, void* out_fp8, float* out_scale, int64_t rows, int C,
+                            float eps, int64_t mod_rows, int64_t first_rows, int64_t mod_ld, float fp8_max, fg_stream_t stream) {
+    if (int e = check_rows("fg_ln_modulate_fp8_bf16", rows, C, mod_rows, first_rows)) return e;
+    FG_CHECK_ARG(x && shift && scale && out_fp8 && out_scale, "fg_ln_modulate_fp8_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(shift) && FG_ALIGNED16(scale) && (((uintptr_t)out_fp8) & 7) == 0 && mod_ld % 8 == 0 &&
+                     fp8_max > 0.f,
+                 "fg_ln_modulate_fp8_bf16: pointers / mod_ld must be 16-byte aligned (out_fp8: 8), fp8_max positive");
+    if (rows == 0) return FG_OK;
+    hipLaunchKernelGGL(ln_modulate_fp8_kernel, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)shift,
+                       (const bf16*)scale, (uint8_t*)out_fp8, out_scale, rows, C, eps, mod_rows, first_rows, mod_ld, fp8_max);
+    return fg_launch_status("fg_ln_modulate_fp8_bf16");
+}
+
+int fg_residual_ln_fp8_bf16(const void* x, const void* y, const void* gate, void* x_out, const void* p0, const void* p1,
+                            void* norm_fp8, float* norm_scale, int mode, int64_t rows, int C, float eps, int64_t mod_rows,
+                            int64_t first_rows, int64_t mod_ld, float fp8_max, fg_stream_t stream) {
+    FG_CHECK_ARG(mode == 0 || mode == 1, "fg_residual_ln_fp8_bf16: mode must be 0 (modulate) or 1 (affine)");
+    const bool need_mod = gate != nullptr || mode == 0;
+    if (int e = check_rows("fg_residual_ln_fp8_bf16", rows, C, need_mod ? mod_rows : 1, need_mod ? first_rows : 0)) return e;
+    FG_CHECK_ARG(x && y && x_out && p0 && p1 && norm_fp8 && norm_scale, "fg_residual_ln_fp8_bf16: null pointer");
+    FG_CHECK_ARG(FG_ALIGNED16(x) && FG_ALIGNED16(y) && FG_ALIGNED16(gate) && FG_ALIGNED16(x_out) && FG_ALIGNED16(p0) &&
+                     FG_ALIGNED16(p1) && (((uintptr_t)norm_fp8) & 7) == 0 && mod_ld % 8 == 0 && fp8_max > 0.f,
+                 "fg_residual_ln_fp8_bf16: pointers / mod_ld must be 16-byte aligned (norm_fp8: 8), fp8_max positive");
+    if (rows == 0) return FG_OK;
+    if (!need_mod) { mod_rows = 1; first_rows = 0; }
+    if (mode == 0)
+        hipLaunchKernelGGL(residual_kernel<0>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)y, (const bf16*)gate, (bf16*)x_out, (const bf16*)p0, (const bf16*)p1,
+                           (bf16*)nullptr, rows, C, eps, mod_rows, first_rows, mod_ld, (uint8_t*)norm_fp8, norm_scale, fp8_max);
+    else
+        hipLaunchKernelGGL(residual_kernel<1>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)y, (const bf16*)gate, (bf16*)x_out, (const bf16*)p0, (const bf16*)p1,
+                           (bf16*)nullptr, rows, C, eps, mod_rows, first_rows, mod_ld, (uint8_t*)norm_fp8, norm_scale, fp8_max);
+    return fg_launch_status("fg_residual_ln_fp8_bf16");
 }
 
 int fg_ln_affine_bf16(const void* x, const void* w, const void* b, void* out, int64_t rows, int C, float eps,

@@ -21,6 +21,8 @@ _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_v
 _SIGNATURES = {
     "fg_ln_modulate_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
     "fg_ln_affine_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "fg_ln_modulate_fp8_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _i64, _f32, _vp],
+    "fg_residual_ln_fp8_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _f32, _vp],
     "fg_gate_residual_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
     "fg_residual_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i64, _i64, _i64, _vp],
     "fg_rmsnorm_rope_bf16": [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f32, _vp],
@@ -207,6 +209,53 @@ def residual_ln_affine(x, y, w, b, eps, mod=None, gate_idx=None, x_out=None, nor
     _call("fg_residual_ln_bf16", _ptr(x), _ptr(y), gate, _ptr(x_out), _ptr(w), _ptr(b), _ptr(norm_out), 1, rows, c,
           eps, *margs, _stream(x))
     return x_out, norm_out
+
+
+def _fp8_rows_out(x):
+    rows, c = _rows(x, "x")
+    return (torch.empty((rows, c), dtype=torch.float8_e4m3fn, device=x.device),
+            torch.empty((rows, 1), dtype=torch.float32, device=x.device))
+
+
+def ln_modulate_fp8(x, mod, shift_idx, scale_idx, eps):
+    """ln_modulate whose result goes to an fp8 Linear only: (x_fp8 (rows, C) e4m3fn, scale (rows, 1) fp32) = what fp8_quant_rows
+    makes of ln_modulate(x, ...), without the bf16 row in HBM."""
+    rows, c = _rows(x, "x")
+    q, sc = _fp8_rows_out(x)
+    _call("fg_ln_modulate_fp8_bf16", _ptr(x), mod.vec(shift_idx), mod.vec(scale_idx), _ptr(q), _ptr(sc), rows, c, eps,
+          *_mod_args(mod, rows), FP8_E4M3FN_MAX, _stream(x))
+    return q, sc
+
+
+def residual_ln_modulate_fp8(x, y, mod, gate_idx, shift_idx, scale_idx, eps, x_out=None, norm_mod=None):
+    """residual_ln_modulate with the normalised row as (fp8 rows, scales): returns x_out, (x_fp8, scale)."""
+    rows, c = _rows(x, "x")
+    _rows(y, "y")
+    norm_mod = mod if norm_mod is None else norm_mod
+    if (norm_mod.mod_rows, norm_mod.first_rows, norm_mod.ld) != (mod.mod_rows, mod.first_rows, mod.ld):
+        raise HipLibraryError("residual_ln_modulate_fp8: gate and norm tables must share rows / first_rows / ld")
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    q, sc = _fp8_rows_out(x)
+    gate = mod.vec(gate_idx) if gate_idx is not None else None
+    _call("fg_residual_ln_fp8_bf16", _ptr(x), _ptr(y), gate, _ptr(x_out), norm_mod.vec(shift_idx), norm_mod.vec(scale_idx),
+          _ptr(q), _ptr(sc), 0, rows, c, eps, *_mod_args(mod, rows), FP8_E4M3FN_MAX, _stream(x))
+    return x_out, (q, sc)
+
+
+def residual_ln_affine_fp8(x, y, w, b, eps, mod=None, gate_idx=None, x_out=None):
+    """residual_ln_affine with the normalised row as (fp8 rows, scales): returns x_out, (x_fp8, scale)."""
+    rows, c = _rows(x, "x")
+    _rows(y, "y")
+    _dev(w, "w"), _dev(b, "b")
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    q, sc = _fp8_rows_out(x)
+    if mod is None:
+        gate, margs = None, (1, 0, 0)
+    else:
+        gate, margs = mod.vec(gate_idx), _mod_args(mod, rows)
+    _call("fg_residual_ln_fp8_bf16", _ptr(x), _ptr(y), gate, _ptr(x_out), _ptr(w), _ptr(b), _ptr(q), _ptr(sc), 1, rows, c,
+          eps, *margs, FP8_E4M3FN_MAX, _stream(x))
+    return x_out, (q, sc)
 
 
 def rmsnorm_rope(x, weight, num_heads, eps, cos=None, sin=None, out=None, grouped=None):

@@ -63,6 +63,7 @@ def gemm_bias_tuned(x, weight, bias):
 # (tools/gemm_ab.py), but the step is power-bound: what the own kernel gains on ffn.2 the library's qkv / ffn.0 lose in clock, so
 # only the removed elementwise traffic shows up.
 GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "fused")
+FP8_FOLD = os.environ.get("FAIRYGEN_FP8_FOLD", "1") != "0"      # fp8 mode: norm kernels emit (e4m3 rows, scales) directly
 
 
 def own_gemm_ok(rows, n, k):
@@ -365,7 +366,10 @@ class WanModel(nn.Module):
             y = gemm_bias(a, sa.o.weight, sa.o.bias) if fp8 is None else lin(a, 1, sa.o.bias)
             if hot:
                 self._hot(f"blocks.{i}.self_attn.o", a, y)
-            x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+            if fp8 is not None and not hot and FP8_FOLD:
+                x, h = hip.residual_ln_affine_fp8(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
+            else:
+                x, h = hip.residual_ln_affine(x, y, blk.norm3.weight, blk.norm3.bias, eps, mod, 2, x_out=x)
         return x, h
 
     # ------------------------------------------------------------------ the 30-block token forward
@@ -414,14 +418,18 @@ class WanModel(nn.Module):
         fp8 = self.fp8_dtype
         ctx8 = hip.fp8_quant_rows(context) if fp8 is not None else None      # the text context is the same for all blocks
         mods = [hip.ModTable((blk.modulation.to(mod_rows_t.dtype) + mod_rows_t).contiguous(), first_rows) for blk in blocks]
-        h = hip.ln_modulate(x, mods[0], 0, 1, eps) if blocks else None
+        # fp8 mode: the four norms of a block feed fp8 Linears only, so they hand over (e4m3 rows, row scales) directly;
+        # a hot-loaded adapter needs the bf16 row too: then the separate quantisation stays
+        fold8 = fp8 is not None and not hot and FP8_FOLD
+        h = (hip.ln_modulate_fp8 if fold8 else hip.ln_modulate)(x, mods[0], 0, 1, eps) if blocks else None
         for i, blk in enumerate(blocks):
             mod = mods[i]
             wqkv, bqkv, wkv_c, bkv_c = blk.fused_weights()
             sa, ca = blk.self_attn, blk.cross_attn
             if fp8 is not None:
                 w8 = blk.fp8_weights(fp8)
-                lin = lambda t, j, bias, act=None: self._scaled_linear(*hip.fp8_quant_rows(t, act), w8[j], bias)      # noqa: E731
+                # t: a bf16 tensor (quantised here) or the (fp8 rows, scales) pair a fused norm kernel already produced
+                lin = lambda t, j, bias, act=None: self._scaled_linear(*(t if isinstance(t, tuple) else hip.fp8_quant_rows(t, act)), w8[j], bias)      # noqa: E731
             own = fp8 is None and not hot and mod.mod_rows in (1, 2)
             if cfg_prefix is not None and i == 0 and "owner" in cfg_prefix:
                 while "x_sa" not in cfg_prefix:      # the other branch is inside block 0's self-attention: let it run
@@ -465,7 +473,10 @@ class WanModel(nn.Module):
                 y = gemm_bias(ac, ca.o.weight, ca.o.bias) if fp8 is None else lin(ac, 4, ca.o.bias)
                 if hot:
                     self._hot(f"blocks.{i}.cross_attn.o", ac, y)
-                x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
+                if fold8:
+                    x, h = hip.residual_ln_modulate_fp8(x, y, mod, None, 3, 4, eps, x_out=x)
+                else:
+                    x, h = hip.residual_ln_modulate(x, y, mod, None, 3, 4, eps, x_out=x)
             # --- ffn (reference :208-209,228)
             if fp8 is not None:      # ffn.0 -> bf16, GELU(tanh) fused into the quantisation of ffn.2's input
                 pre = lin(h, 5, blk.ffn[0].bias)
@@ -490,7 +501,9 @@ class WanModel(nn.Module):
                 if f is None:
                     f = hip.activation(pre.clone(), "gelu_tanh")
                 self._hot(f"blocks.{i}.ffn.2", f, y)
-            if i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
+            if i + 1 < len(blocks) and fold8:
+                x, h = hip.residual_ln_modulate_fp8(x, y, mod, 5, 0, 1, eps, x_out=x, norm_mod=mods[i + 1])
+            elif i + 1 < len(blocks):   # x += gate_mlp*y fused with the NEXT block's modulate(norm1(x))
                 x, h = hip.residual_ln_modulate(x, y, mod, 5, 0, 1, eps, x_out=x, norm_out=h, norm_mod=mods[i + 1])
             else:
                 x = hip.gate_residual(x, y, mod, 5, out=x)

@@ -70,6 +70,17 @@ int fg_residual_ln_bf16(const void* x, const void* y, const void* gate, void* x_
                         int64_t rows, int C, float eps,
                         int64_t mod_rows, int64_t first_rows, int64_t mod_ld, fg_stream_t stream);
 
+/* fg_ln_modulate_bf16 / fg_residual_ln_bf16 for a norm whose ONLY consumer is an fp8 Linear (the fp8 mode of the DiT blocks:
+ * AutoWrappedLinear.fp8_linear, core/vram/layers.py:331-342, after models/wan_video_dit.py:224-228): instead of the bf16 row, the
+ * normalised row leaves as e4m3 bytes out_fp8 / norm_fp8 (rows, C) and one fp32 scale per row — bit for bit what
+ * fg_fp8_quant_rows_bf16 (act 0) makes of the bf16 row, without writing and re-reading it.  fp8_max: 448 for e4m3fn. */
+int fg_ln_modulate_fp8_bf16(const void* x, const void* shift, const void* scale, void* out_fp8, float* out_scale,
+                            int64_t rows, int C, float eps, int64_t mod_rows, int64_t first_rows, int64_t mod_ld,
+                            float fp8_max, fg_stream_t stream);
+int fg_residual_ln_fp8_bf16(const void* x, const void* y, const void* gate, void* x_out, const void* p0, const void* p1,
+                            void* norm_fp8, float* norm_scale, int mode, int64_t rows, int C, float eps,
+                            int64_t mod_rows, int64_t first_rows, int64_t mod_ld, float fp8_max, fg_stream_t stream);
+
 /* nn.Linear of the DiT blocks (models/wan_video_dit.py:130-133,156-159,208-209): c[M,N] = a[M,K] w[N,K]^T + bias[N], bf16 in and
  * out, fp32 accumulation, bias added to the accumulator before the one bf16 rounding (as the library GEMM does).  a has leading
  * dimension lda, c ldc (elements); w is the row-major (out_features, in_features) weight; N %% 256 == 0, K %% 64 == 0.

@@ -215,6 +215,38 @@ def test_fp8_quant_rows(hip, C, act):
         assert (got.cpu().float() - want.float()).abs().max().item() <= 0.07 * want.float().abs().max().item()
 
 
+def test_fp8_output_norms(hip):
+    """fg_ln_modulate_fp8_bf16 / fg_residual_ln_fp8_bf16: the norm kernels of the fp8 Linear mode hand the normalised row over as
+    (e4m3 rows, row scales); must equal fg_fp8_quant_rows_bf16 applied to the bf16 result of the plain norm kernels, byte for byte
+    (fp8_linear's activation side, core/vram/layers.py:331-342, after models/wan_video_dit.py:224-228)."""
+    rows, C = 77, 3072
+    x, y = seeded((1, rows, C), 51), seeded((1, rows, C), 52)
+    table = seeded((2, 6, C), 53, scale=0.5)
+    table[1, 0, 7] = table[0, 3, 9] = 900.0                     # shifts that push row maxima beyond fp8_max: scales > 1 on those rows
+    mod = hip.ModTable(dev(table), 30)
+    w, b = (1 + 0.1 * seeded((C,), 54)).to(torch.bfloat16), (0.1 * seeded((C,), 55)).to(torch.bfloat16)
+    b[11] = 900.0
+
+    def same(pair, bf16_rows):
+        q, sc = hip.fp8_quant_rows(bf16_rows)
+        assert torch.equal(pair[0].view(torch.uint8).cpu(), q.view(torch.uint8).cpu()) and torch.equal(pair[1].cpu(), sc.cpu())
+        assert pair[1].max().item() > 1.0
+
+    same(hip.ln_modulate_fp8(dev(x), mod, 0, 1, 1e-6), hip.ln_modulate(dev(x), mod, 0, 1, 1e-6))
+    xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, 5, 0, 1, 1e-6)
+    xo8, pair = hip.residual_ln_modulate_fp8(dev(x), dev(y), mod, 5, 0, 1, 1e-6)
+    assert torch.equal(xo8, xo)
+    same(pair, no)
+    xo, no = hip.residual_ln_affine(dev(x), dev(y), dev(w), dev(b), 1e-6, mod, 2)
+    xo8, pair = hip.residual_ln_affine_fp8(dev(x), dev(y), dev(w), dev(b), 1e-6, mod, 2)
+    assert torch.equal(xo8, xo)
+    same(pair, no)
+    xo, no = hip.residual_ln_modulate(dev(x), dev(y), mod, None, 3, 4, 1e-6)
+    xo8, pair = hip.residual_ln_modulate_fp8(dev(x), dev(y), mod, None, 3, 4, 1e-6)
+    assert torch.equal(xo8, xo)
+    same(pair, no)
+
+
 def test_activations_and_cfg_euler(hip):
     x = seeded((3, 1000, 8), 14, scale=3.0)
     assert_close_bf16(hip.activation(dev(x).clone(), "silu"), F.silu(x), 1.0, "silu", max_mismatch=0.05)          # __expf vs libm: rare 1-ulp flips
