@@ -73,8 +73,11 @@ def scaled_mm(a8, b8t, scale_a, scale_b, bias, out_dtype):
 def fp8_linear(x, weight, bias, dtype=torch.float8_e4m3fn):
     """AutoWrappedLinear.fp8_linear, core/vram/layers.py:321-357: per-row dynamic activation scale (only ever scaling
     DOWN: clamp(min=1)), weights cast to fp8 with unit scale, bf16 bias, row-wise scaled matmul, result in x's dtype.
-    PARITY UNPINNED against an execution of the reference: its torch._scaled_mm call with row-wise scales is rejected by
-    the CPU backend here (ordinary RuntimeError), so there is no golden vector; restated line by line."""
+    Pinned on the shape the CPU backend of the build container accepts: torch._scaled_mm with (rows, 1) / (1, out) scales runs
+    there only for one row x one output, and 64 such calls of the reference's own method (oracle/gen_fp8_linear_1x1.py, K = 3072 and
+    14336, row maxima below / around / above fp8_max) are reproduced bit for bit (tests/test_oracle_golden.py).  Multi-row calls are
+    rejected there (ordinary RuntimeError), so anything beyond one row per call — there is no cross-row arithmetic in the method —
+    has no vector of its own."""
     origin_dtype, origin_shape = x.dtype, x.shape
     inp = x.reshape(-1, origin_shape[-1])
     x_max = torch.max(torch.abs(inp), dim=-1, keepdim=True).values

@@ -229,6 +229,26 @@ def test_fp8_linear_mode_vs_oracle(tiny_dit):
     assert (got.float().cpu() - cpu.float()).abs().max().item() <= 2.0 ** -7 * cpu.float().abs().max().item()
 
 
+def test_fp8_linear_vs_reference_golden(tiny_dit, golden):
+    """The product's fp8 Linear (fg_fp8_quant_rows_bf16 + torch._scaled_mm on the device, WanModel._scaled_linear) against the
+    outputs of the REFERENCE's own fp8_linear (oracle/gen_fp8_linear_1x1.py: the 1-row x 1-output calls this container's CPU backend
+    accepts).  All cases of a reduction length go through ONE call — rows = the cases' activation rows, weight rows = the cases'
+    weights — and entry (i, i) is case i (per-row scales: rows do not mix).  fp8 x fp8 products are exact in fp32; only the fp32
+    summation order differs between the CPU kernel and the MFMA one: <= 1 bf16 ulp, and equal in nearly all cases."""
+    from fairygen_amd import hip as fh
+    m, _, _ = tiny_dit
+    g = golden("fp8_linear_1x1.safetensors")
+    for k in (3072, 14336):
+        x, w, b, want = g[f"x_{k}"].cuda(), g[f"w_{k}"].cuda(), g[f"b_{k}"].cuda(), g[f"out_{k}"]
+        q, sc = fh.fp8_quant_rows(x.unsqueeze(0))
+        ref_sc = torch.clamp(x.float().abs().amax(-1, keepdim=True).to(torch.bfloat16) / 448.0, min=1.0).float()
+        assert torch.equal(sc, ref_sc) and (sc > 1).any() and (sc == 1).any()
+        got = torch.diagonal(m._scaled_linear(q, sc, w.to(torch.float8_e4m3fn), b)[0]).float().cpu()
+        err = (got - want.float()).abs()
+        assert (err <= 2.0 ** -7 * want.float().abs().clamp_min(2.0 ** -6)).all(), err.max().item()
+        assert (got == want.float()).float().mean().item() >= 0.9
+
+
 def test_medium_dit_block_stack_vs_oracle():
     """Full-width heads (24 x 128, dim 3072) but 2 layers / small ffn, ragged token count, vs the oracle."""
     from fairygen_amd.wan_video_dit import WanModel

@@ -103,6 +103,21 @@ def test_fp8_linear_restatement():
     assert rel < 0.08                                         # e4m3 weights of magnitude 0.05: ~4 % mean error
 
 
+def test_fp8_linear_vs_reference_golden(golden):
+    """The reference's own AutoWrappedLinear.fp8_linear (core/vram/layers.py:321-357), run by oracle/gen_fp8_linear_1x1.py on the one
+    shape this container's CPU torch._scaled_mm accepts with its (rows, 1) / (1, out) scales — one row x one output — for 64 cases
+    (K = 3072 and 14336, row maxima below, around and far above fp8_max): the restatement must reproduce every output, calling it
+    both one case at a time and with all rows / all weight rows at once (the diagonal: per-row scales do not mix rows)."""
+    g = golden("fp8_linear_1x1.safetensors")
+    for k in (3072, 14336):
+        x, w, b, want = g[f"x_{k}"], g[f"w_{k}"], g[f"b_{k}"], g[f"out_{k}"]
+        assert (x.float().abs().amax(-1) > 448).any() and (x.float().abs().amax(-1) < 448).any()
+        one = torch.cat([wan_dit.fp8_linear(x[i:i + 1], w[i:i + 1], b[i:i + 1]).reshape(1) for i in range(x.shape[0])])
+        assert torch.equal(one, want)
+        full = wan_dit.fp8_linear(x, w, b)                      # (cases, cases): entry (i, i) is case i
+        assert torch.equal(torch.diagonal(full), want)
+
+
 def test_sliding_window_model_fn(golden):
     g = golden("serving.safetensors")
     cfg = synthetic.TINY_DIT_KWARGS
