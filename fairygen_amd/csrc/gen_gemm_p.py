@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Generator of the PERSISTENT form of the hand-scheduled DiT bias-GEMM (gemm_p_kernel in csrc/dit_gemm.hip):
-C[M,N] = A[M,K] W[N,K]^T + bias (+ epilogue), bf16 in / out, fp32 accumulate.
+"""Generator of the hand-scheduled body of gemm_p_kernel (csrc/dit_gemm.hip), the persistent DiT GEMM behind fg_gemm_epilogue_bf16:
+C[M,N] = A[M,K] W[N,K]^T + bias (+ residual epilogue), bf16 in / out, fp32 accumulate (nn.Linear / GateModule of the DiT block,
+models/wan_video_dit.py:130-133,188-193,208-209,225-228).
 
-    python3 gen_gemm_p.py --nb 4|3 [--stamp] > gemm_p{nb}_asm.inc
+    python3 gen_gemm_p.py --nb 4 --tail 1 | --nb 3  [--stamp] [--pf-dist N] [--ablate nodma|samek|l1]      (run by the Makefile)
 
-Same core as gen_gemm_w4.py (4 waves, one per SIMD; 256 activation rows x NB*64 weight rows x 64 k per step; LDS-DMA into 2
-stages; fragments one k-step ahead, across the barrier; every fragment read feeds NB or 4 MFMAs) plus what the data-parallel
-form measured as missing: ONE workgroup per CU walks a list of output tiles (written to LDS by the C++ wrapper:
-XCD-aware, grouped raster), the first k-slice of the next tile is fetched while the epilogue of the current one runs, lane
-constants are set up once, the first k-step of a tile multiplies onto C = 0 (no accumulator clearing), and a 256 x 192 tile
-(--nb 3) is available for the N = 3072 shapes (1712 tiles = 6.7 rounds of 256 CUs instead of 5.02 -> 6).
-Epilogue modes (FLAGS): 0 = bias; 2 = x + gate * bf16(acc + bias) with the residual x read in place and gate per token class
-(GateModule of the DiT block, models/wan_video_dit.py:188-193,225,228); 3 = x + bf16(acc + bias) (cross-attention residual :226).
+Core: 4 waves, one per SIMD, all 512 registers owned by the asm; 256 activation rows x NB*64 weight rows x 64 k per step; operand
+tiles by LDS-DMA into a ring of LDS stages; fragments read one k-step ahead, across the barrier; every fragment read feeds NB or
+4 MFMAs.  Around it (DESIGN.md §5 has the measurements behind each point):
+  * ONE workgroup per CU walks a list of 64-byte tile records the C++ wrapper wrote to LDS (operand / output / bias bases, valid
+    bytes, k range, gate slice, prefetch lanes); the next tile's record and first k-slice are fetched BEFORE the current tile's
+    epilogue, the bias words when a tile starts; the first k-step multiplies onto C = 0;
+  * cooperative L2 prefetch: the CUs of an XCD that share an operand slice each pull a part of its rows pf_dist slices ahead with
+    EXEC-masked dummy loads, and the step's wait is counted so the prefetch never blocks;
+  * epilogue through a per-wave LDS transpose: every global access is a dwordx4 of 4 rows x 256 contiguous bytes; FLAGS 0 = bias,
+    2 = x + gate * bf16(acc + bias) (x read in place, gate per token class), 3 = x + bf16(acc + bias); KIND 2 records (k-range
+    pieces of the last round's tiles) store their fp32 accumulators raw for gemm_reduce_kernel;
+  * --tail 1: a second body for 256 x 64 column pieces of the last round's tiles, on a 3-stage ring (its shorter steps would be
+    DMA-latency-bound on 2 stages); --nb 3: the 256 x 192 tile for N % 256 != 0.
+--stamp: in-kernel cycle counters per phase (tools/gemm_ab.py --stamp-lib-p); --ablate: timing-only builds (wrong results) used to
+locate the k-step's cost; neither is part of the product library.
 """
 import argparse
 import sys
