@@ -59,6 +59,8 @@ OOB = 0x80000000
 class Cfg:
     dma_step = 2.0                       # MFMA gaps between two LDS-DMA pieces (--dma-step)
     dma_first = 1                        # gap of the first piece
+    serp = 1                             # MFMA order inside a k-substep: 1 = boustrophedon over the X fragments: consecutive MFMAs always share an
+                                         # input operand (+0.5 % clock at the power cap, measured); 0 = row-major
     pf_coop = 1                          # 1: the CUs of an XCD that share an operand slice pull a part of its rows each (EXEC-masked): every
                                          #    8th activation row (8 tiles of a row block), every 4th weight row; 2: activation rows only
     pf_dist = 2                          # L2 prefetch distance in k-slices beyond the slice the step's LDS-DMA fetches (0 = off)
@@ -272,6 +274,19 @@ def frag_read(C, op, blk, fset, stage, ks):
     return f"ds_read_b128 {vr(dst, 4)}, {vr(base)} offset:{blk * 4096 + extra}"
 
 
+def mfma_order(C, idx):
+    """(ni, mi) of the idx-th MFMA of a k-substep.  serp: boustrophedon over mi, so that consecutive MFMAs always share one input
+    operand (the W fragment inside a row of four, the X fragment at the turn)."""
+    ni, j = idx >> 2, idx & 3
+    return ni, (3 - j if (C.serp and (ni & 1)) else j)
+
+
+def x_last_use(C, mi):
+    """Position within a k-substep of the last MFMA that reads X fragment mi."""
+    last_row = C.nb - 1
+    return 4 * last_row + (3 - mi if (C.serp and (last_row & 1)) else mi)
+
+
 def mfma(ni, mi, fset, zero_c=False):
     d = ar(acc(ni, mi), 16)
     return f"v_mfma_f32_32x32x16_bf16 {d}, {vr(fset + 4 * ni, 4)}, {vr(fset + 16 + 4 * mi, 4)}, {'0' if zero_c else d}"
@@ -289,7 +304,7 @@ def build_iteration(E, C, stage, first, budget):
                 if busy_blk is None or (first and busy_blk == 0):
                     earliest = 0
                 else:
-                    earliest = g16 * busy_blk + (4 * blk + 3 if op == "W" else 4 * (C.nb - 1) + blk) + 2
+                    earliest = g16 * busy_blk + (4 * blk + 3 if op == "W" else x_last_use(C, blk)) + 2
                 need = g16 * need_blk + (4 * blk if op == "W" else blk)
                 deadline = min(need - 4, C.gaps - 4)
                 add(Item(f"rd{ks}{op}{blk}", [frag_read(C, op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest), lds=1))
@@ -308,7 +323,7 @@ def build_iteration(E, C, stage, first, budget):
     lds_issued, lds_done, done_at = 0, 0, {}
     for g in range(C.gaps):
         b, idx = g // g16, g % g16
-        ni, mi = idx >> 2, idx & 3
+        ni, mi = mfma_order(C, idx)
         if not (first and b == 0):
             ks = b - 1
             if b >= 1:
@@ -348,7 +363,7 @@ def emit_kloop(E, C, budget):
         E.e(f"s_cbranch_scc1 {done}" if stage != order[-1] else f"s_cbranch_scc0 {loop}")
     E.e(f"{done}:")
     for idx in range(C.g16):
-        E.e(mfma(idx >> 2, idx & 3, F1))
+        E.e(mfma(*mfma_order(C, idx), F1))
     if C.ring == 3:      # the last steps fetched past the end of K: those pieces must be down before the next tile's slices target the ring
         E.e("s_waitcnt vmcnt(0)")
 
@@ -614,15 +629,18 @@ def main():
     ap.add_argument("--ablate", default="")
     ap.add_argument("--pf-dist", type=int, default=Cfg.pf_dist)
     ap.add_argument("--pf-coop", type=int, default=Cfg.pf_coop)
+    ap.add_argument("--serp", type=int, default=Cfg.serp)
     a = ap.parse_args()
     Cfg.dma_step, Cfg.dma_first, Cfg.ablate, Cfg.pf_dist, Cfg.pf_coop = a.dma_step, a.dma_first, a.ablate, a.pf_dist, a.pf_coop
+    Cfg.serp = a.serp
     E = generate(a.nb, a.stamp, a.budget, a.tail)
     name = f"FG_GEMM_P{a.nb}{a.tail or ''}"
     out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} --tail {a.tail} : do not edit", f"#define {name}_ASM \\"]
     for ln in E.lines:
         out.append('    "%s\\n\\t" \\' % ln)
     out.append('    ""')
-    regs = [f'"v{i}"' for i in range(256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(SB, SB + NSREG + (4 if a.stamp else 0))]
+    # v251..v254 are not used by the body: left to the compiler (the stamp build keeps values across the asm statement)
+    regs = [f'"v{i}"' for i in range(256) if not 251 <= i <= 254] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(SB, SB + NSREG + (4 if a.stamp else 0))]
     out.append(f"#define {name}_CLOBBERS " + ", ".join(regs) + ', "vcc", "scc", "memory"')
     print("\n".join(out))
 
