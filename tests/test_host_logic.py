@@ -34,6 +34,34 @@ def test_no_cpu_fallback():
         hip.activation(q, "silu")
     with pytest.raises(hip.HipLibraryError):
         hip.vae_rmsnorm_silu(q, q[0, 0], True)
+    w, b = seeded((256, 256), 2), seeded((256,), 3)
+    with pytest.raises(hip.HipLibraryError, match="no CPU fallback"):
+        hip.gemm_epilogue(q, w, b)
+    with pytest.raises(hip.HipLibraryError):
+        hip.ln_modulate_fp8(q, None, 0, 1, 1e-6)
+
+
+def test_gemm_entry_point_validation_and_backend_policy():
+    """fg_gemm_epilogue_bf16's argument checks run on the host (no launch); which DiT Linears go to it is shape policy."""
+    import ctypes
+    from fairygen_amd import wan_video_dit as wd
+    lib = hip.load()
+    p16 = ctypes.c_void_p(16)
+    call = lambda M, N, K, mode=0, gate=None, rows=1, ld=0, ws=None: lib.fg_gemm_epilogue_bf16(      # noqa: E731
+        p16, K, p16, p16, p16, N, M, N, K, mode, gate, rows, ld, 0, ws, None)
+    assert call(512, 250, 256) == -1 and b"N % 256" in lib.fg_last_error()
+    assert call(512, 256, 192) == -1 and b"K % 128" in lib.fg_last_error()
+    assert call(512, 256, 256, mode=1) == -1 and b"mode must be" in lib.fg_last_error()
+    assert call(512, 256, 256, mode=2) == -1 and b"gate table" in lib.fg_last_error()
+    assert call(512, 256, 256, ws=ctypes.c_void_p(8)) == -1 and b"workspace" in lib.fg_last_error()
+    assert lib.fg_gemm_workspace_bytes(27280, 3072, 14336) == 256 * 256 * 256 * 4      # one fp32 tile per CU
+    assert lib.fg_gemm_workspace_bytes(600, 576, 384) == 0                             # 192-column tiling: no k-split
+    # the policy: shapes the persistent kernel takes AND fills the chip with (two rounds of 256 CUs of 256 x 256 tiles)
+    assert wd.GEMM_BACKEND in ("fused", "fused+ffn2", "all", "lib")
+    if wd.GEMM_BACKEND != "lib":
+        assert wd.own_gemm_ok(27280, 3072, 3072) and wd.own_gemm_ok(13640, 3072, 3072) and wd.own_gemm_ok(27280, 3072, 14336)
+        assert not wd.own_gemm_ok(6820, 3072, 3072)            # a 1/4 token shard: 324 tiles, left to the library's tuned solutions
+        assert not wd.own_gemm_ok(27280, 128, 128) and not wd.own_gemm_ok(27280, 3072, 3000)
 
 
 def test_argument_validation_through_the_c_abi():
