@@ -212,7 +212,7 @@ def cpu_baseline(args, n_tokens, frames, steps, grid):
     oracle/gen_config1.py, where the reference itself took 25.0 s/clip and this port 24.1 s on config 1, and at the headline
     N = 27 280 by oracle/gen_config3_forward.py) timed on the host cores on a bounded sample of the SAME workload: ONE of the
     30 full-width DiT blocks at the REAL token count (no N^2 extrapolation: x30 blocks x2 CFG branches x steps is a plain
-    repeat count) + a full-width VAE38 decode of a (1,48,2,4,4) latent scaled by pixel-frames."""
+    repeat count) + a full-width VAE38 decode of a (1,48,2,12,12) latent scaled by pixel-frames."""
     from fairygen_amd import synthetic
     from fairygen_amd.loader import TI2V_5B_DIT_KWARGS
     from oracle import wan_dit, wan_vae
@@ -240,15 +240,19 @@ def cpu_baseline(args, n_tokens, frames, steps, grid):
             how = f"1 of 30 full-width DiT blocks at {ns} tokens ({t_block:.1f}s, SDPA {t_attn:.1f}s) scaled to N={n_tokens} (GEMM~N, SDPA~N^2)"
         vsd = synthetic.random_state_dict(synthetic.vae_shapes(), seed=1234, only_prefix="model.dec") \
             | synthetic.random_state_dict({"model.conv2.weight": (48, 48, 1, 1, 1), "model.conv2.bias": (48,)}, seed=2)
-        z = seeded((1, 48, 2, 4, 4), 10)
+        # a (2, 12, 12) latent = 5 frames of 192 x 192: big enough that the per-op overhead of a tiny tensor on 128 threads no longer
+        # dominates (a (2, 4, 4) sample cost 4x more per pixel-frame and swung between 3 and 7 s from run to run); timed after a tiny
+        # warm-up call (thread pools, lazy initialisation)
+        wan_vae.decode(vsd, seeded((1, 48, 1, 2, 2), 11))
+        z = seeded((1, 48, 2, 12, 12), 10)
         t0 = time.perf_counter()
         wan_vae.decode(vsd, z)
         t_vae_s = time.perf_counter() - t0
     lat_t = (frames - 1) // 4 + 1
-    vae_scale = (args.height // 16) * (args.width // 16) * (4 * lat_t - 3) / (4 * 4 * 5)
+    vae_scale = (args.height // 16) * (args.width // 16) * (4 * lat_t - 3) / (12 * 12 * 5)
     t_clip = t_forward * 2 * steps + t_vae_s * vae_scale * (2.21 if not args.untiled and args.height > 480 else 1.0)
     return {"value": frames / t_clip, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{how} x30 x2 x{steps} steps + full-width VAE38 decode of a (1,48,2,4,4) latent ({t_vae_s:.1f}s) "
+            "sample": f"{how} x30 x2 x{steps} steps + full-width VAE38 decode of a (1,48,2,12,12) latent ({t_vae_s:.1f}s) "
                       f"scaled by pixel-frames; sec/clip = {t_clip:.0f}"}
 
 
