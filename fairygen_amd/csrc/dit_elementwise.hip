@@ -242,7 +242,9 @@ __global__ FG_ROW_BOUNDS void residual_kernel(const bf16* __restrict__ x, const 
 // HBM-bound norm takes at N = 27 280).  F32TAB true: `ct` is ONE interleaved fp32 table (rows, head_dim/2, {cos, sin}) =
 // the fp64 table rounded once, rotation as two fp32 FMAs: the bf16 result differs from the fp64 one only where the
 // exact value lies within ~2e-7 relative of a bf16 rounding boundary (measured in tests/test_hip_kernels.py).
-template <bool F32TAB>
+// PLAIN: plain rows (group_cols == C) and head_dim a power of two — the runtime `/ group_cols` and `% head_dim` (an integer division
+// each, per vector: about as many VALU instructions as the norm itself) become a constant and a mask.
+template <bool F32TAB, bool PLAIN = false>
 __global__ FG_ROW_BOUNDS void rmsnorm_rope_kernel(const bf16* __restrict__ x, int64_t ldx,
                                                            const bf16* __restrict__ w, const void* __restrict__ ctv,
                                                            const void* __restrict__ stv, bf16* __restrict__ out,
@@ -267,7 +269,8 @@ __global__ FG_ROW_BOUNDS void rmsnorm_rope_kernel(const bf16* __restrict__ x, in
     const bool hoist = F32TAB && ctv != nullptr && (512 % head_dim) == 0;
     f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
     if (hoist) {
-        const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (((lane * 8) % head_dim) >> 1)) * 2);
+        const int d_lane = PLAIN ? ((lane * 8) & (head_dim - 1)) : ((lane * 8) % head_dim);
+        const f32x4* tp = reinterpret_cast<const f32x4*>(static_cast<const float*>(ctv) + (row * half + (d_lane >> 1)) * 2);
         h0 = tp[0];
         h1 = tp[1];
     }
@@ -280,7 +283,7 @@ __global__ FG_ROW_BOUNDS void rmsnorm_rope_kernel(const bf16* __restrict__ x, in
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = rbf(rbf(r.v[i][j] * rinv) * (float)wv[j]);
             if (ctv != nullptr) {
-                const int d0 = (vi * 8) % head_dim;          // channel within the head, multiple of 8
+                const int d0 = PLAIN ? ((vi * 8) & (head_dim - 1)) : ((vi * 8) % head_dim);          // channel within the head, multiple of 8
                 if (F32TAB) {
                     f32x4 t0 = h0, t1 = h1;                  // (c0,s0,c1,s1) (c2,s2,c3,s3)
                     if (!hoist) {
@@ -308,7 +311,7 @@ __global__ FG_ROW_BOUNDS void rmsnorm_rope_kernel(const bf16* __restrict__ x, in
                 }
             }
             // column block g = col / group_cols goes to its own (rows, out_ld) plane (group_cols == C: plain rows)
-            const int col = vi * 8, g = col / group_cols;
+            const int col = vi * 8, g = PLAIN ? 0 : col / group_cols;
             st8(out + g * out_group_stride + row * out_ld + (col - g * group_cols), o);
         }
     }
@@ -479,14 +482,14 @@ int fg_rmsnorm_rope_bf16(const void* x, int64_t ldx, const void* weight, const v
                      FG_ALIGNED16(cos_tab) && FG_ALIGNED16(sin_tab),
                  "fg_rmsnorm_rope_bf16: pointers / ldx must be 16-byte aligned");
     if (rows == 0) return FG_OK;
-    if (table_f32)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
-                           (int64_t)C);
-    else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<false>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
-                           (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, C, (int64_t)0,
-                           (int64_t)C);
+    const int hd = C / num_heads;
+    const bool plain = (hd & (hd - 1)) == 0;          // plain rows + power-of-two head_dim: the division-free instantiation
+#define FG_ROPE_LAUNCH(TAB, PL)                                                                                                  \
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<TAB, PL>), row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,    \
+                       (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, hd, eps, C, (int64_t)0, (int64_t)C)
+    if (table_f32) { if (plain) FG_ROPE_LAUNCH(true, true); else FG_ROPE_LAUNCH(true, false); }
+    else { if (plain) FG_ROPE_LAUNCH(false, true); else FG_ROPE_LAUNCH(false, false); }
+#undef FG_ROPE_LAUNCH
     return fg_launch_status("fg_rmsnorm_rope_bf16");
 }
 
@@ -507,11 +510,11 @@ int fg_rmsnorm_rope_grouped_bf16(const void* x, int64_t ldx, const void* weight,
                  "fg_rmsnorm_rope_grouped_bf16: pointers / ldx must be 16-byte aligned");
     if (rows == 0) return FG_OK;
     if (table_f32)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<true>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+        hipLaunchKernelGGL((rmsnorm_rope_kernel<true, false>), row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
                            (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
                            out_group_stride, out_ld);
     else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<false>, row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+        hipLaunchKernelGGL((rmsnorm_rope_kernel<false, false>), row_grid(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
                            (const bf16*)weight, cos_tab, sin_tab, (bf16*)out, rows, C, C / num_heads, eps, group_cols,
                            out_group_stride, out_ld);
     return fg_launch_status("fg_rmsnorm_rope_grouped_bf16");
