@@ -55,13 +55,13 @@ def gemm_bias_tuned(x, weight, bias):
 
 
 # The DiT Linears that run on this repo's own persistent MFMA kernel (fg_gemm_epilogue_bf16, csrc/gen_gemm_p.py) — also seams for
-# bench.py.  FAIRYGEN_GEMM = "fused" (default): the 3072 x 3072 projections — self-attention o (gate_msa) and cross-attention o, whose
-# output goes straight into the residual stream (the GateModule add happens in the GEMM's store, so the following LayerNorm reads
-# x once instead of x and y), and the cross-attention q; "fused+ffn2": ffn.2 (gate_mlp) too; "all": qkv as well; "lib": everything
-# on hipBLASLt.  ffn.0 stays on the library in every mode (GELU in its epilogue).  Measured in the 704x1280x121 denoise step, same
-# box: lib 790.9, fused 787.2, fused+ffn2 790.1, all 791.3 ms — kernel for kernel the own GEMM is at or above the library's rate
-# (tools/gemm_ab.py), but the step is power-bound: what the own kernel gains on ffn.2 the library's qkv / ffn.0 lose in clock, so
-# only the removed elementwise traffic shows up.
+# bench.py.  FAIRYGEN_GEMM = "fused" (default): the projections whose output goes straight into the residual stream — self-attention
+# o (gate_msa), cross-attention o, ffn.2 (gate_mlp): the GateModule add happens in the GEMM's store, so the following LayerNorm
+# reads x once instead of x and y — and the cross-attention q; "fused-ffn2": without ffn.2; "all": qkv as well; "lib": everything on
+# hipBLASLt.  ffn.0 stays on the library in every mode (GELU in its epilogue).  Measured in the 704x1280x121 denoise step on one box
+# with the final kernels: lib 793.9, fused-ffn2 781.4, fused 777.1 ms.  The MFMA-dense part of the step is power-bound (the board sits
+# at its 1 400 W limit), so most of what shows up is the removed elementwise traffic: "all" (qkv moved too) measured no better than
+# "fused".
 GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "fused")
 FP8_FOLD = os.environ.get("FAIRYGEN_FP8_FOLD", "1") != "0"      # fp8 mode: norm kernels emit (e4m3 rows, scales) directly
 
@@ -490,7 +490,7 @@ class WanModel(nn.Module):
                 f = gemm_bias_gelu(h, blk.ffn[0].weight, blk.ffn[0].bias)
             else:
                 f = hip.activation(gemm_bias(h, blk.ffn[0].weight, blk.ffn[0].bias), "gelu_tanh")
-            if own and GEMM_BACKEND in ("fused+ffn2", "all") and own_gemm_ok(f.shape[1], c, f.shape[2]):      # x += gate_mlp * ffn.2(f) in the store
+            if own and GEMM_BACKEND != "fused-ffn2" and own_gemm_ok(f.shape[1], c, f.shape[2]):      # x += gate_mlp * ffn.2(f) in the store
                 x = gemm_residual(x, f, blk.ffn[2].weight, blk.ffn[2].bias, mod, 5)
                 if i + 1 < len(blocks):
                     h = hip.ln_modulate(x, mods[i + 1], 0, 1, eps, out=h)

@@ -57,7 +57,7 @@ def test_gemm_entry_point_validation_and_backend_policy():
     assert lib.fg_gemm_workspace_bytes(27280, 3072, 14336) == 256 * 256 * 256 * 4      # one fp32 tile per CU
     assert lib.fg_gemm_workspace_bytes(600, 576, 384) == 0                             # 192-column tiling: no k-split
     # the policy: shapes the persistent kernel takes AND fills the chip with (two rounds of 256 CUs of 256 x 256 tiles)
-    assert wd.GEMM_BACKEND in ("fused", "fused+ffn2", "all", "lib")
+    assert wd.GEMM_BACKEND in ("fused", "fused-ffn2", "all", "lib")
     if wd.GEMM_BACKEND != "lib":
         assert wd.own_gemm_ok(27280, 3072, 3072) and wd.own_gemm_ok(13640, 3072, 3072) and wd.own_gemm_ok(27280, 3072, 14336)
         assert not wd.own_gemm_ok(6820, 3072, 3072)            # a 1/4 token shard: 324 tiles, left to the library's tuned solutions
