@@ -12,5 +12,5 @@ void fg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int fg_version(void) { return 2; }
+extern "C" int fg_version(void) { return 3; }
 extern "C" const char* fg_last_error(void) { return g_err; }

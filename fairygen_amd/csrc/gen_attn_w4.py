@@ -2,7 +2,7 @@
 """Generator of the hand-scheduled main body of attn_fwd_w4_kernel (csrc/attention.hip): gfx950 assembly, emitted as ONE inline
 asm statement whose registers are all owned here (512-entry register file: 256 arch VGPRs + 256 AGPRs, one wave per SIMD).
 
-    python3 gen_attn_w4.py [--prescale 0|1] > attn_w4_asm.inc          (run by the Makefile)
+    python3 gen_attn_w4.py --prescale 0|1 --name PREFIX > attn_w4[p]_asm.inc          (run by the Makefile, once per form)
 
 Structure (the "4 waves x 64 query rows" form of /opt/skills/guides/cdna_hip_programming.md, Appendix B, built on this
 repo's own LDS images and operand maps from attn_fwd_kernel<8,1>):
@@ -16,8 +16,12 @@ repo's own LDS images and operand maps from attn_fwd_kernel<8,1>):
     O^T += V(t)^T P(t)^T beside the row max of tile t+1 and the K(t+2) fragment reads; every other instruction is dealt to
     an MFMA gap by the list scheduler below (issue-cost budget per gap; at most one transcendental per gap);
   * deferred rescale (threshold 2^6) as an out-of-line rare path; ragged last tile masked by an out-of-line block.
---prescale 1: Q^T is multiplied by scale*log2(e) once (re-rounded to bf16) and -max is the C operand of the first MFMA of
-every score chain, so the exponent argument needs no VALU op (64 v_fma fewer per tile and wave).
+--prescale 1: Q^T is multiplied by scale*log2(e) once and -max is the C operand of the first MFMA of every score chain, so the
+exponent argument needs no VALU op (64 v_fma fewer per tile and wave).  The product is re-rounded to bf16, which is EXACT only when
+scale*log2(e) is a power of two: the launcher (attention.hip) takes this form for such scales only — measured on peaked rows with a
+general scale the second rounding costs 4x the error of the plain form (score error ~ |score| * 2^-9), see DESIGN.md §5 — and the
+host arranges a power-of-two scale for self-attention by folding the remaining factor into q's RoPE table.
+--prescale 0: exponent argument by v_fma on the fp32 scores of the exact bf16 operands, for every other scale.
 """
 import argparse
 import sys
@@ -734,6 +738,7 @@ def main():
     global GAP_BUDGET, DMA_EVERY, STAMP
     ap = argparse.ArgumentParser()
     ap.add_argument("--prescale", type=int, default=1)
+    ap.add_argument("--name", default="FG_ATTN_W4", help="prefix of the generated macros (<name>_ASM, <name>_CLOBBERS)")
     ap.add_argument("--ablate", default="", help="comma list of timing-only ablations (wrong results): dma,barrier,vmcnt,exp,lds,max,valu")
     ap.add_argument("--stamp", action="store_true", help="diagnostic build: cycle / clock stamps of the tile loop into the output (corrupts it)")
     ap.add_argument("--budget", type=int, default=GAP_BUDGET)
@@ -748,14 +753,13 @@ def main():
     if a.report:
         for p, ld in enumerate(loads):
             print(f"step phase {p}: gap loads {ld} (max {max(ld)}, sum {sum(ld)})", file=sys.stderr)
-    out = ["// GENERATED by gen_attn_w4.py --prescale %d : do not edit" % a.prescale,
-           "#define FG_ATTN_W4_PRESCALE %d" % a.prescale,
-           "#define FG_ATTN_W4_ASM \\"]
+    out = ["// GENERATED by gen_attn_w4.py --prescale %d --name %s : do not edit" % (a.prescale, a.name),
+           "#define %s_ASM \\" % a.name]
     for ln in E.lines:
         out.append('    "%s\\n\\t" \\' % ln)
     out.append('    ""')
     regs = [f'"v{i}"' for i in range(256)] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(SBASE, SBASE + NSREG)]
-    out.append("#define FG_ATTN_W4_CLOBBERS " + ", ".join(regs) + ', "vcc", "scc", "memory"')
+    out.append(f"#define {a.name}_CLOBBERS " + ", ".join(regs) + ', "vcc", "scc", "memory"')
     print("\n".join(out))
 
 

@@ -14,7 +14,8 @@ tiles by LDS-DMA into a ring of LDS stages; fragments read one k-step ahead, acr
   * cooperative L2 prefetch: the CUs of an XCD that share an operand slice each pull a part of its rows pf_dist slices ahead with
     EXEC-masked dummy loads, and the step's wait is counted so the prefetch never blocks;
   * epilogue through a per-wave LDS transpose: every global access is a dwordx4 of 4 rows x 256 contiguous bytes; FLAGS 0 = bias,
-    2 = x + gate * bf16(acc + bias) (x read in place, gate per token class), 3 = x + bf16(acc + bias); KIND 2 records (k-range
+    2 = x + gate * bf16(acc + bias) (x read in place, gate per token class), 3 = x + bf16(acc + bias), 4 = bf16(gelu_tanh(bf16(acc +
+    bias))); KIND 2 records (k-range
     pieces of the last round's tiles) store their fp32 accumulators raw for gemm_reduce_kernel;
   * --tail 1: a second body for 256 x 64 column pieces of the last round's tiles, on a 3-stage ring (its shorter steps would be
     DMA-latency-bound on 2 stages); --nb 3: the 256 x 192 tile for N % 256 != 0.
@@ -53,6 +54,20 @@ V_PW, V_PX, V_PD = 248, 249, 250   # L2 prefetch: byte offset of this lane's row
                                    # lane and k-slice), dummy destination
 V_T = 224          # setup temporaries v224..230
 V_REC = 144        # v144, v146..161: tile record loads (outside the epilogue)
+V_SC = 252         # fp8 form only: v252..255 = the activation row scales of the lane's four 32-row blocks (loaded when the tile starts)
+FP8 = False        # --dtype fp8: e4m3 operands (one byte per element, 128 k per LDS row), v_mfma_f32_32x32x64_f8f6f4, row-scale epilogue
+
+
+def configure_fp8():
+    """Register map of the e4m3 form.  A fragment is 8 registers (32 bytes: k = 64 s + 32 hh + 0..31 of the 128-k LDS row, s the k-substep),
+    so the two fragment sets take v0..127; everything the epilogue alone uses (unpacked bias, y, the first residual buffer, record loads,
+    setup temporaries) lives in that area, dead outside the k-loop."""
+    globals().update(F0=0, F1=64, V_WRD=128, V_XRD=136, V_DW=144, V_DX=152, V_COLB=160, V_LW=161, V_LR=162, V_SOFF=163, V_RROW=164,
+                     V_GOFF=165, V_TB=166, V_BIASRAW=176, V_YR=64, V_XA=96, V_XB=208, V_G0=240, V_G1=244, V_PW=248, V_PX=249,
+                     V_PD=250, V_T=208, V_REC=64, V_SC=252, FP8=True)
+    globals().update(V_GC=96, V_GT=104)
+
+
 OOB = 0x80000000
 
 
@@ -68,8 +83,10 @@ class Cfg:
 
     def __init__(self, nb):
         self.nb = nb                     # 32-row weight blocks per wave
-        self.g16 = nb * 4                # MFMAs per k-step
-        self.gaps = 4 * self.g16         # MFMAs per K-step of 64
+        self.g16 = nb * 4                # MFMAs per k-substep
+        self.nsub = 2 if FP8 else 4      # k-substeps (MFMA K) per LDS stage of 128 bytes per row: 4 x 16 bf16 / 2 x 64 e4m3
+        self.fr = 8 if FP8 else 4        # registers per fragment
+        self.gaps = self.nsub * self.g16 # MFMAs per stage
         self.npw = 2 * nb                # weight LDS-DMA pieces per wave per tile
         # LDS ring of operand stages.  256-/192-column tiles: 2 stages of 64 KiB.  The 64-column tail tile moves 40 KiB per k-step
         # for a quarter of the MFMAs, so with 2 stages its step would last one LDS-DMA round trip (measured: ~2 000 cycles, as long
@@ -114,7 +131,11 @@ def emit_setup(E, C, first=True):
     E.e(f"s_lshl_b32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, 14")
     E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, {C.xoff}")
     for ks in range(4):
-        E.e(f"v_or_b32 {vr(T1)}, {2 * ks}, {vr(HH)}")
+        if FP8:      # address register 2s + c: 16-byte chunk 4s + 2hh + c of the row (k-substep s, half c of the lane's 32 bytes)
+            E.e(f"v_lshlrev_b32 {vr(T1)}, 1, {vr(HH)}")
+            E.e(f"v_or_b32 {vr(T1)}, {4 * (ks >> 1) + (ks & 1)}, {vr(T1)}")
+        else:
+            E.e(f"v_or_b32 {vr(T1)}, {2 * ks}, {vr(HH)}")
         E.e(f"v_xor_b32 {vr(T1)}, {vr(T1)}, {vr(SW)}")
         E.e(f"v_lshl_add_u32 {vr(T1)}, {vr(T1)}, 4, {vr(T0)}")
         E.e(f"v_add_u32 {vr(V_WRD + ks)}, {sr(S['TMP0'])}, {vr(T1)}")
@@ -265,13 +286,16 @@ def pf_ops(C):
 
 
 def frag_read(C, op, blk, fset, stage, ks):
-    dst = fset + (0 if op == "W" else 16) + 4 * blk
+    """The ds_read_b128 lines that fetch fragment `blk` of operand `op` for k-substep `ks` (one line; two for the 32-byte e4m3 fragment)."""
+    dst = fset + (0 if op == "W" else 4 * C.fr) + C.fr * blk
     if C.ring == 3:      # base set 0 = stage 0 (stage 1 through the immediate offset), set 1 = stage 2
         bset, extra = (1, 0) if stage == 2 else (0, stage * C.stage_bytes)
     else:
         bset, extra = stage, 0
-    base = (V_WRD if op == "W" else V_XRD) + 4 * bset + ks
-    return f"ds_read_b128 {vr(dst, 4)}, {vr(base)} offset:{blk * 4096 + extra}"
+    base = (V_WRD if op == "W" else V_XRD) + 4 * bset
+    if FP8:
+        return [f"ds_read_b128 {vr(dst + 4 * c, 4)}, {vr(base + 2 * ks + c)} offset:{blk * 4096 + extra}" for c in range(2)]
+    return [f"ds_read_b128 {vr(dst, 4)}, {vr(base + ks)} offset:{blk * 4096 + extra}"]
 
 
 def mfma_order(C, idx):
@@ -289,6 +313,8 @@ def x_last_use(C, mi):
 
 def mfma(ni, mi, fset, zero_c=False):
     d = ar(acc(ni, mi), 16)
+    if FP8:      # e4m3 x e4m3 (cbsz = blgp = 0), 64 k per instruction, 16 passes
+        return f"v_mfma_f32_32x32x64_f8f6f4 {d}, {vr(fset + 8 * ni, 8)}, {vr(fset + 32 + 8 * mi, 8)}, {'0' if zero_c else d}"
     return f"v_mfma_f32_32x32x16_bf16 {d}, {vr(fset + 4 * ni, 4)}, {vr(fset + 16 + 4 * mi, 4)}, {'0' if zero_c else d}"
 
 
@@ -297,8 +323,8 @@ def build_iteration(E, C, stage, first, budget):
     items = []
     add = items.append
     g16 = C.g16
-    sets = [F1, F0, F1, F0]
-    for ks, (fset, busy_blk, need_blk) in enumerate([(F0, None, 1), (F1, 0, 2), (F0, 1, 3), (F1, 2, 4)]):
+    sets = [F1, F0, F1, F0][:C.nsub]
+    for ks, (fset, busy_blk, need_blk) in enumerate([(F0, None, 1), (F1, 0, 2), (F0, 1, 3), (F1, 2, 4)][:C.nsub]):
         for op, nblk in (("W", C.nb), ("X", 4)):
             for blk in range(nblk):
                 if busy_blk is None or (first and busy_blk == 0):
@@ -306,18 +332,20 @@ def build_iteration(E, C, stage, first, budget):
                 else:
                     earliest = g16 * busy_blk + (4 * blk + 3 if op == "W" else x_last_use(C, blk)) + 2
                 need = g16 * need_blk + (4 * blk if op == "W" else blk)
-                deadline = min(need - 4, C.gaps - 4)
-                add(Item(f"rd{ks}{op}{blk}", [frag_read(C, op, blk, fset, stage, ks)], 2, earliest=earliest, deadline=max(deadline, earliest), lds=1))
+                deadline = min(need - (2 if FP8 else 4), C.gaps - (2 if FP8 else 4))
+                lines = frag_read(C, op, blk, fset, stage, ks)
+                add(Item(f"rd{ks}{op}{blk}", lines, 2 * len(lines), earliest=earliest, deadline=max(deadline, earliest), lds=len(lines)))
     pieces = [("W", i) for i in range(C.npw)] + [("X", i) for i in range(8)]
     dma_step = min(C.dma_step, 0.5 * C.gaps / len(pieces))       # all pieces inside the first half of the step
     for n, (op, i) in enumerate(pieces if C.ablate != "nodma" else []):
         g0 = C.dma_first + int(n * dma_step)
-        add(Item(f"dma{op}{i}", dma_piece(C, op, i, (stage + C.ring - 1) % C.ring), 12, earliest=g0, deadline=g0 + 8))
+        add(Item(f"dma{op}{i}", dma_piece(C, op, i, (stage + C.ring - 1) % C.ring), 12, earliest=g0, deadline=g0 + (4 if FP8 else 8)))
     n_pf = 0
     if C.pf_dist and C.ablate != "nodma":      # after every LDS-DMA piece in program order: the step's wait is vmcnt(n_pf)
-        last = C.dma_first + int((len(pieces) - 1) * dma_step) + 8
+        last = C.dma_first + int((len(pieces) - 1) * dma_step) + (4 if FP8 else 8)
         for n, op in enumerate(pf_ops(C)):
-            add(Item(f"pf{op}", prefetch_lines(C, op, C.pf_dist), 8, earliest=min(last + 1 + 2 * n, C.gaps - 2), deadline=min(last + 9 + 2 * n, C.gaps - 1)))
+            add(Item(f"pf{op}", prefetch_lines(C, op, C.pf_dist), 8, earliest=min(last + 1 + 2 * n, C.gaps - 2),
+                     deadline=min(last + (5 if FP8 else 9) + 2 * n, C.gaps - 1)))
             n_pf += 1
     gaps, load = schedule(items, C.gaps, budget)
     lds_issued, lds_done, done_at = 0, 0, {}
@@ -394,7 +422,8 @@ def qoff(q):
     return 64 * (q >> 2) + 16 * (q & 3)
 
 
-N_PREFETCH = lambda C: C.nb * 4 + 2          # noqa: E731  VMEM loads of emit_tile_prefetch
+N_PREFETCH = lambda C: C.nb * 4 + 2 + (4 if FP8 else 0)          # noqa: E731  VMEM loads of emit_tile_prefetch
+S_SCB, S_MLAST = S["ST1"], SB + 62           # fp8 form: base of the activation row scales (64-bit), M - 1  (the stamp counters' SGPRs: no --stamp there)
 
 
 def emit_tile_prefetch(E, C):
@@ -405,6 +434,66 @@ def emit_tile_prefetch(E, C):
         E.e(f"buffer_load_dwordx2 {vr(V_BIASRAW + 2 * q, 2)}, {vr(V_COLB)}, {sr(S['BD'], 4)}, 0 offen offset:{qoff(q)}")
     E.e(f"buffer_load_dwordx4 {vr(V_G0, 4)}, {vr(V_GOFF)}, {sr(S['GD'], 4)}, 0 offen")
     E.e(f"buffer_load_dwordx4 {vr(V_G1, 4)}, {vr(V_GOFF)}, {sr(S['GD'], 4)}, {sr(S['GLD'])} offen")
+    if FP8:      # scale_a of the lane's accumulator rows m0 + 128 (wave & 1) + 32 mi + r (clamped to the last row: those rows are never stored)
+        E.e(f"v_mbcnt_lo_u32_b32 {vr(V_TB)}, -1, 0")
+        E.e(f"v_mbcnt_hi_u32_b32 {vr(V_TB)}, -1, {vr(V_TB)}")
+        E.e(f"v_and_b32 {vr(V_TB)}, 31, {vr(V_TB)}")
+        E.e(f"s_and_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 1")
+        E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, 7")
+        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {sr(S['M0ROW'])}")
+        E.e(f"v_add_u32 {vr(V_TB)}, {sr(S['TMP0'])}, {vr(V_TB)}")
+        for mi in range(4):
+            E.e(f"v_add_u32 {vr(V_TB + 1)}, {32 * mi}, {vr(V_TB)}")
+            E.e(f"v_min_u32 {vr(V_TB + 1)}, {sr(S_MLAST)}, {vr(V_TB + 1)}")
+            E.e(f"v_lshlrev_b32 {vr(V_TB + 2 + mi)}, 2, {vr(V_TB + 1)}")
+        for mi in range(4):
+            E.e(f"global_load_dword {vr(V_SC + mi)}, {vr(V_TB + 2 + mi)}, {sr(S_SCB, 2)}")
+
+
+# GELU(tanh) in the row-major phase of the epilogue (FLAGS 4: ffn.0, models/wan_video_dit.py:208-209): y * sigmoid(2u),
+# u = sqrt(2/pi) (y + 0.044715 y^3), as y * rcp(1 + exp2(y * (c1 + c2 y^2))) with c1 = -2 sqrt(2/pi) log2(e), c2 = 0.044715 c1: packed
+# fp32 for the polynomial, v_exp_f32 / v_rcp_f32 (1 ulp) for the rest; y = -large gives y * rcp(inf) = -0, y = +large gives y * 1.
+V_GC = V_XA            # v176..181: (c1, c1), (c2, c2), (1, 1)   [the residual buffers are idle in this mode]
+V_GT = V_XA + 8        # v184..199: temporaries of two word pairs in flight
+GELU_C1 = -2.0 * 0.7978845608028654 * 1.4426950408889634
+
+
+def f32_bits(x):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def emit_gelu_consts(E):
+    for i, val in enumerate((GELU_C1, GELU_C1, GELU_C1 * 0.044715, GELU_C1 * 0.044715, 1.0, 1.0)):
+        E.e(f"v_mov_b32 {vr(V_GC + i)}, 0x{f32_bits(val):08x}")
+
+
+def emit_gelu_words(E, words):
+    """Four packed-bf16 words in place.  Two words (4 values) are advanced together so that a transcendental's result is first read
+    two instructions later (trans -> VALU forwarding hazard on gfx940+)."""
+    for w0, w1 in ((words[0], words[1]), (words[2], words[3])):
+        xa, xb, ta, tb = V_GT, V_GT + 2, V_GT + 4, V_GT + 6
+        for w, x in ((w0, xa), (w1, xb)):
+            E.e(f"v_lshlrev_b32 {vr(x)}, 16, {vr(w)}")
+            E.e(f"v_and_b32 {vr(x + 1)}, 0xffff0000, {vr(w)}")
+        for x, t in ((xa, ta), (xb, tb)):
+            E.e(f"v_pk_mul_f32 {vr(t, 2)}, {vr(x, 2)}, {vr(x, 2)}")
+        for x, t in ((xa, ta), (xb, tb)):
+            E.e(f"v_pk_fma_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(V_GC + 2, 2)}, {vr(V_GC, 2)}")
+        for x, t in ((xa, ta), (xb, tb)):
+            E.e(f"v_pk_mul_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(x, 2)}")
+        for t in (ta, ta + 1, tb, tb + 1):
+            E.e(f"v_exp_f32 {vr(t)}, {vr(t)}")
+        E.e("s_nop 0")
+        for t in (ta, tb):
+            E.e(f"v_pk_add_f32 {vr(t, 2)}, {vr(t, 2)}, {vr(V_GC + 4, 2)}")
+        for t in (ta, ta + 1, tb, tb + 1):
+            E.e(f"v_rcp_f32 {vr(t)}, {vr(t)}")
+        E.e("s_nop 0")
+        for x, t in ((xa, ta), (xb, tb)):
+            E.e(f"v_pk_mul_f32 {vr(x, 2)}, {vr(x, 2)}, {vr(t, 2)}")
+        for w, x in ((w0, xa), (w1, xb)):
+            E.e(f"v_cvt_pk_bf16_f32 {vr(w)}, {vr(x)}, {vr(x + 1)}")
 
 
 def emit_epilogue(E, C, n_dma):
@@ -433,6 +522,10 @@ def emit_epilogue(E, C, n_dma):
             for j in range(4):
                 E.e(f"v_accvgpr_read_b32 {vr(TB + j)}, {ar(acc(ni, mi, 4 * g + j))}")
             E.e("s_nop 0")
+            if FP8:      # torch._scaled_mm: (acc * scale_a[row] * scale_b[col]) + bias, scale_b = 1: one fp32 rounding per operation
+                sel = f"op_sel:[0,{mi & 1}] op_sel_hi:[1,{mi & 1}]"          # both halves take dword (mi & 1) of the scale pair
+                E.e(f"v_pk_mul_f32 {vr(TB, 2)}, {vr(TB, 2)}, {vr(V_SC + (mi & 2), 2)} {sel}")
+                E.e(f"v_pk_mul_f32 {vr(TB + 2, 2)}, {vr(TB + 2, 2)}, {vr(V_SC + (mi & 2), 2)} {sel}")
             E.e(f"v_pk_add_f32 {vr(TB, 2)}, {vr(TB, 2)}, {vr(BIAS + 4 * q, 2)}")
             E.e(f"v_pk_add_f32 {vr(TB + 2, 2)}, {vr(TB + 2, 2)}, {vr(BIAS + 4 * q + 2, 2)}")
             E.e(f"v_cvt_pk_bf16_f32 {vr(TB + 4)}, {vr(TB)}, {vr(TB + 1)}")
@@ -452,11 +545,13 @@ def emit_epilogue(E, C, n_dma):
         E.e(f"buffer_store_dwordx4 {vr(V_YR + 4 * it, 4)}, {vr(V_SOFF)}, {sr(S['CD'], 4)}, {sr(S['TMP0'])} offen")
         E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {sr(S['TMP2'])}")
 
-    plain, resid, done, raw = E.label("epiplain"), E.label("epiresid"), E.label("epidone"), E.label("epiraw")
+    plain, resid, done, raw, gelu = E.label("epiplain"), E.label("epiresid"), E.label("epidone"), E.label("epiraw"), E.label("epigelu")
     E.e(f"s_cmp_eq_u32 {sr(S['KIND'])}, 2")
     E.e(f"s_cbranch_scc1 {raw}")
     E.e(f"s_cmp_lt_u32 {sr(S['FLAGS'])}, 2")
     E.e(f"s_cbranch_scc1 {plain}")
+    E.e(f"s_cmp_eq_u32 {sr(S['FLAGS'])}, 4")
+    E.e(f"s_cbranch_scc1 {gelu}")
     E.e(f"s_cmp_eq_u32 {sr(S['FLAGS'])}, 3")
     E.e(f"s_cbranch_scc1 {resid}")
     for gated in (True, False):
@@ -498,18 +593,23 @@ def emit_epilogue(E, C, n_dma):
                     E.e(f"v_cvt_pk_bf16_f32 {vr(yw)}, {vr(TB)}, {vr(TB + 1)}")
                 store(it)
         E.e(f"s_branch {done}")
-    # ---- plain: bias only
-    E.e(f"{plain}:")
-    write_block(0)
-    for mi in range(4):
-        read_block()
-        if mi < 3:
-            write_block(mi + 1)
-        E.e("s_waitcnt lgkmcnt(0)")
-        for it in range(8):
-            store(it)
-    E.e("s_waitcnt vmcnt(32)")                       # the LDS-DMA of the next tile's first k-slice has landed (no stall this late)
-    E.e(f"s_branch {done}")
+    # ---- plain: bias only; gelu: GELU(tanh) of the bf16-rounded y, rounded again (nn.Linear, then nn.GELU: two bf16 op boundaries)
+    for act in (False, True):
+        E.e(f"{gelu if act else plain}:")
+        if act:
+            emit_gelu_consts(E)
+        write_block(0)
+        for mi in range(4):
+            read_block()
+            if mi < 3:
+                write_block(mi + 1)
+            E.e("s_waitcnt lgkmcnt(0)")
+            for it in range(8):
+                if act:
+                    emit_gelu_words(E, [V_YR + 4 * it + j for j in range(4)])
+                store(it)
+        E.e("s_waitcnt vmcnt(32)")                       # the LDS-DMA of the next tile's first k-slice has landed (no stall this late)
+        E.e(f"s_branch {done}")
     # ---- a k-range piece: the fp32 accumulators as they stand -> the piece's workspace slot (CD), straight from the AGPRs.
     # Layout: dwordx4 number s = (ni*4 + mi)*4 + g of a wave at byte ((wave*(NB*16) + s)*64 + lane)*16: fg_gemm_reduce_kernel
     # (dit_gemm.hip) adds the pieces of a tile in k order and applies the epilogue.
@@ -542,6 +642,10 @@ def emit_program(E, C, stamp, budget, first):
     E.e(f"s_mov_b32 {sr(S['GLD'])}, %8")
     E.e(f"s_mov_b32 {sr(S['GD'] + 2)}, %9")
     E.e(f"s_mov_b32 {sr(S['BD'] + 2)}, {C.nb * 2 * 32 * 2}")
+    if FP8:      # %10 base of the row scales (fp32, one per activation row), %11 M - 1
+        assert not stamp, "the fp8 form keeps its scale base in the stamp counters' SGPRs"
+        E.e(f"s_mov_b64 {sr(S_SCB, 2)}, %10")
+        E.e(f"s_mov_b32 {sr(S_MLAST)}, %11")
     end = E.label("pend")
     tile_loop = E.label("ptile")
     nodma = E.label("pnodma")
@@ -630,17 +734,22 @@ def main():
     ap.add_argument("--pf-dist", type=int, default=Cfg.pf_dist)
     ap.add_argument("--pf-coop", type=int, default=Cfg.pf_coop)
     ap.add_argument("--serp", type=int, default=Cfg.serp)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
     a = ap.parse_args()
+    if a.dtype == "fp8":
+        configure_fp8()
     Cfg.dma_step, Cfg.dma_first, Cfg.ablate, Cfg.pf_dist, Cfg.pf_coop = a.dma_step, a.dma_first, a.ablate, a.pf_dist, a.pf_coop
     Cfg.serp = a.serp
     E = generate(a.nb, a.stamp, a.budget, a.tail)
-    name = f"FG_GEMM_P{a.nb}{a.tail or ''}"
-    out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} --tail {a.tail} : do not edit", f"#define {name}_ASM \\"]
+    name = f"FG_GEMM_{'Q' if FP8 else 'P'}{a.nb}{a.tail or ''}"
+    out = [f"// GENERATED by gen_gemm_p.py --nb {a.nb} --tail {a.tail} --dtype {a.dtype} : do not edit", f"#define {name}_ASM \\"]
     for ln in E.lines:
         out.append('    "%s\\n\\t" \\' % ln)
     out.append('    ""')
-    # v251..v254 are not used by the body: left to the compiler (the stamp build keeps values across the asm statement)
-    regs = [f'"v{i}"' for i in range(256) if not 251 <= i <= 254] + [f'"a{i}"' for i in range(256)] + [f'"s{i}"' for i in range(SB, SB + NSREG + (4 if a.stamp else 0))]
+    # not used by the body and left to the compiler (it needs a VGPR for SGPR spills; the stamp build keeps values across the asm statement)
+    free_v = (251,) if FP8 else (251, 252, 253, 254)
+    regs = [f'"v{i}"' for i in range(256) if i not in free_v] + [f'"a{i}"' for i in range(256)] + \
+           [f'"s{i}"' for i in range(SB, SB + NSREG + (4 if a.stamp else 1 if FP8 else 0))]
     out.append(f"#define {name}_CLOBBERS " + ", ".join(regs) + ', "vcc", "scc", "memory"')
     print("\n".join(out))
 

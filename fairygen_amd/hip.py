@@ -13,7 +13,7 @@ import torch
 _LIB_PATH = os.environ.get("FAIRYGEN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfairygen_hip.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -30,8 +30,8 @@ _SIGNATURES = {
     "fg_copy_groups_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _vp],
     "fg_fp8_quant_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp],
     "fg_act_bf16": [_vp, _vp, _i64, _i32, _vp],
-    "fg_gemm_bias_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "fg_gemm_epilogue_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _vp, _vp],
+    "fg_gemm_fp8_bf16": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _vp, _vp],
     "fg_attn_fwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _f32, _vp, _i64, _vp],
     "fg_cfg_euler_bf16": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp],
     "fg_vae_rmsnorm_silu_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
@@ -315,27 +315,46 @@ def copy_groups(src, src_group_stride, src_ld, dst, dst_group_stride, dst_ld, gr
     return dst
 
 
-def gemm_bias(x, weight, bias, out=None):
-    """x (..., K) with dense last dim (rows may be strided: 2-D view with stride(0) = lda) @ weight (N, K)^T + bias -> (..., N)."""
-    _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
-    k = x.shape[-1]
-    n = weight.shape[0]
-    if weight.shape != (n, k) or not weight.is_contiguous() or bias.shape != (n,) or x.stride(-1) != 1:
-        raise HipLibraryError("gemm_bias: weight must be a contiguous (N, K) tensor, bias (N,), x dense in its last dim")
-    x2 = x.reshape(-1, k) if x.is_contiguous() else (x.squeeze(0) if x.dim() == 3 else x)
-    if x2.dim() != 2:
-        raise HipLibraryError("gemm_bias: strided input must be 2-D (rows, K) or (1, rows, K)")
-    m, lda = x2.shape[0], x2.stride(0)
-    out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
-    _call("fg_gemm_bias_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 0, _stream(x))
+_gemm_workspace = {}      # (device, stream) -> scratch for the k-split pieces of a GEMM's last round (one fp32 tile per CU, reused)
+
+
+def _gemm_ws(x, m, n, k_bytes, workspace):
+    """The k-split scratch, only where fg_gemm_* would use it (at least 96 k-steps of 128 operand bytes)."""
+    need = load().fg_gemm_workspace_bytes(m, n, k_bytes) if workspace and k_bytes // 128 >= 96 else 0
+    if need <= 0:
+        return None
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)      # concurrent streams must not share scratch
+    ws = _gemm_workspace.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _gemm_workspace[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    return ws
+
+
+def _gemm_out(name, x, m, n, out, residual):
+    if out is None:
+        if residual:
+            raise HipLibraryError(f"{name}: residual=True needs the contiguous residual stream as `out`")
+        return torch.empty(x.shape[:-1] + (n,), dtype=torch.bfloat16, device=x.device)
+    _dev(out, "out")
+    if not out.is_contiguous() or out.numel() != m * n:
+        raise HipLibraryError(f"{name}: `out` must be a contiguous bf16 tensor of {m} x {n} elements")
     return out
 
 
-_gemm_workspace = {}      # (device, stream) -> scratch for the k-split pieces of a GEMM's last round (64 MiB, reused)
+def _gemm_mode(name, residual, mod, gate_idx, act, n):
+    """(mode, gate pointer, gate rows, gate ld, first rows) of the fg_gemm_* epilogue."""
+    if act not in (None, "gelu_tanh") or (act is not None and residual):
+        raise HipLibraryError(f"{name}: act must be None or 'gelu_tanh', and not combined with residual=True")
+    if residual and mod is not None:
+        if mod.mod_rows not in (1, 2) or mod.c != n:
+            raise HipLibraryError(f"{name}: the gate table must have 1 or 2 rows of N values")
+        return 2, mod.vec(gate_idx), mod.mod_rows, mod.ld, mod.first_rows
+    return (3 if residual else 4 if act else 0), None, 1, n, 0
 
 
-def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=None, workspace=True):
-    """Linear on the persistent MFMA kernel.  residual=False: out = x @ weight^T + bias.  residual=True: `out` holds the residual
+def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=None, workspace=True, act=None):
+    """Linear on the persistent MFMA kernel.  residual=False: out = act(x @ weight^T + bias), act None or "gelu_tanh" (applied to the
+    bf16-rounded Linear output and rounded again, like nn.Linear followed by nn.GELU).  residual=True: `out` holds the residual
     stream and becomes out + gate * (x @ weight^T + bias) (gate = vector gate_idx of `mod`, or 1 when mod is None), with the
     reference's rounding points (GateModule, models/wan_video_dit.py:188-193).  workspace=False: no k-split of the last round's tiles
     (every element one k-ordered accumulation, independent of the row count)."""
@@ -348,27 +367,34 @@ def gemm_epilogue(x, weight, bias, out=None, residual=False, mod=None, gate_idx=
     if x2.dim() != 2:
         raise HipLibraryError("gemm_epilogue: strided input must be 2-D (rows, K) or (1, rows, K)")
     m, lda = x2.shape[0], x2.stride(0)
-    if residual:
-        if out is None or not out.is_contiguous() or out.numel() != m * n:
-            raise HipLibraryError("gemm_epilogue: residual=True needs the contiguous residual stream as `out`")
-        _dev(out, "out")
-    else:
-        out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device) if out is None else out
-    ws = None
-    need = load().fg_gemm_workspace_bytes(m, n, k) if workspace else 0
-    if need > 0:
-        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)      # concurrent streams must not share scratch
-        ws = _gemm_workspace.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _gemm_workspace[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
-    if residual and mod is not None:
-        if mod.mod_rows not in (1, 2) or mod.c != n:
-            raise HipLibraryError("gemm_epilogue: the gate table must have 1 or 2 rows of N values")
-        _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 2, mod.vec(gate_idx),
-              mod.mod_rows, mod.ld, mod.first_rows, _ptr(ws) if ws is not None else None, _stream(x))
-    else:
-        _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, 3 if residual else 0, None,
-              1, n, 0, _ptr(ws) if ws is not None else None, _stream(x))
+    out = _gemm_out("gemm_epilogue", x, m, n, out, residual)
+    mode, gate, gate_rows, gate_ld, first = _gemm_mode("gemm_epilogue", residual, mod, gate_idx, act, n)
+    ws = _gemm_ws(x, m, n, 2 * k, workspace)
+    _call("fg_gemm_epilogue_bf16", _ptr(x2), lda, _ptr(weight), _ptr(bias), _ptr(out), n, m, n, k, mode, gate, gate_rows, gate_ld, first,
+          _ptr(ws), _stream(x))
+    return out
+
+
+def gemm_fp8(x_fp8, scale_a, weight_fp8, bias, out=None, residual=False, mod=None, gate_idx=None, workspace=True, act=None, lead_shape=None):
+    """torch._scaled_mm(x_fp8, weight_fp8.T, scale_a (rows, 1), ones (1, out), bias, out_dtype=bf16) of AutoWrappedLinear.fp8_linear
+    (core/vram/layers.py:343-357) on the persistent kernel's e4m3 form, with the epilogues of gemm_epilogue.  x_fp8: (rows, K)
+    float8_e4m3fn, scale_a: (rows, 1) fp32 (both from fp8_quant_rows / the fp8-output norm kernels), weight_fp8: (N, K) float8_e4m3fn.
+    Returns (*lead_shape, N) bf16 (default lead_shape: (rows,))."""
+    _dev(x_fp8, "x_fp8", torch.float8_e4m3fn), _dev(weight_fp8, "weight_fp8", torch.float8_e4m3fn), _dev(bias, "bias")
+    _dev(scale_a, "scale_a", torch.float32)
+    if x_fp8.dim() != 2 or x_fp8.stride(1) != 1 or not weight_fp8.is_contiguous() or weight_fp8.dim() != 2:
+        raise HipLibraryError("gemm_fp8: x_fp8 must be (rows, K) with a dense last dim, weight_fp8 a contiguous (N, K) tensor")
+    (m, k), n = x_fp8.shape, weight_fp8.shape[0]
+    if weight_fp8.shape[1] != k or bias.shape != (n,) or scale_a.numel() != m or not scale_a.is_contiguous():
+        raise HipLibraryError("gemm_fp8: shapes of weight_fp8 (N, K), bias (N,), scale_a (rows, 1) do not match x_fp8 (rows, K)")
+    lead = (m,) if lead_shape is None else tuple(lead_shape)
+    if out is None and not residual:
+        out = torch.empty(lead + (n,), dtype=torch.bfloat16, device=x_fp8.device)
+    out = _gemm_out("gemm_fp8", x_fp8, m, n, out, residual)
+    mode, gate, gate_rows, gate_ld, first = _gemm_mode("gemm_fp8", residual, mod, gate_idx, act, n)
+    ws = _gemm_ws(x_fp8, m, n, k, workspace)
+    _call("fg_gemm_fp8_bf16", _ptr(x_fp8), x_fp8.stride(0), _ptr(scale_a), _ptr(weight_fp8), _ptr(bias), _ptr(out), n, m, n, k, mode, gate,
+          gate_rows, gate_ld, first, _ptr(ws), _stream(x_fp8))
     return out
 
 
@@ -417,8 +443,17 @@ def _ld_rows(t, name):
 _attn_workspace = {}      # (device, stream) -> scratch tensor for the split-KV partials (grown on demand, reused)
 
 
-def attention(q, k, v, num_heads, out=None):
-    """softmax(q k^T / sqrt(d)) v, "b s (n d)" in and out (AttentionModule semantics)."""
+def pow2_softmax_scale(head_dim):
+    """(scale', f) with scale' * log2(e) = the power of two next to head_dim^-0.5 * log2(e) and f = their ratio (1.0201 for d = 128):
+    softmax(scale' (f q) k^T) = softmax(q k^T / sqrt(d)), and fg_attn_fwd_bf16 runs its pre-multiplied form exactly for scale'."""
+    import math
+    sl = float(head_dim) ** -0.5 * math.log2(math.e)
+    p = 2.0 ** round(math.log2(sl))
+    return p / math.log2(math.e), sl / p
+
+
+def attention(q, k, v, num_heads, out=None, scale=None):
+    """softmax(scale q k^T) v with scale = 1 / sqrt(d) by default, "b s (n d)" in and out (AttentionModule semantics)."""
     ldq, ldk, ldv = _ld_rows(q, "q"), _ld_rows(k, "k"), _ld_rows(v, "v")
     b, nq, hd = q.shape
     nkv = k.shape[1]
@@ -430,7 +465,7 @@ def attention(q, k, v, num_heads, out=None):
     if need > 0 and (ws is None or ws.numel() < need):
         ws = _attn_workspace[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
     _call("fg_attn_fwd_bf16", _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(out), b, nq, nkv, num_heads, d,
-          float(d) ** -0.5, _ptr(ws) if need > 0 else None, need, _stream(q))
+          float(d) ** -0.5 if scale is None else float(scale), _ptr(ws) if need > 0 else None, need, _stream(q))
     return out
 
 

@@ -54,25 +54,31 @@ def gemm_bias_tuned(x, weight, bias):
     return tuning.linear(x, weight, bias)      # table: better hipBLASLt solution at the multi-GPU shard sizes
 
 
-# The DiT Linears that run on this repo's own persistent MFMA kernel (fg_gemm_epilogue_bf16, csrc/gen_gemm_p.py) — also seams for
-# bench.py.  FAIRYGEN_GEMM = "fused" (default): the projections whose output goes straight into the residual stream — self-attention
-# o (gate_msa), cross-attention o, ffn.2 (gate_mlp): the GateModule add happens in the GEMM's store, so the following LayerNorm
-# reads x once instead of x and y — and the cross-attention q; "fused-ffn2": without ffn.2; "all": qkv as well; "lib": everything on
-# hipBLASLt.  ffn.0 stays on the library in every mode (GELU in its epilogue).  Measured in the 704x1280x121 denoise step on one box
-# with the final kernels: lib 793.9, fused-ffn2 781.4, fused 777.1 ms.  The MFMA-dense part of the step is power-bound (the board sits
-# at its 1 400 W limit), so most of what shows up is the removed elementwise traffic: "all" (qkv moved too) measured no better than
-# "fused".
-GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "fused")
+# The DiT Linears that run on this repo's own persistent MFMA kernel (fg_gemm_epilogue_bf16 / fg_gemm_fp8_bf16, csrc/gen_gemm_p.py) —
+# also seams for bench.py.  FAIRYGEN_GEMM = "all" (default): every Linear of the 30 blocks — qkv, the self-attention o with the
+# gate_msa add in its store, cross-attention q and o (+ residual), ffn.0 with GELU(tanh) in its epilogue, ffn.2 with the gate_mlp add —
+# so a denoise step launches no library GEMM inside the blocks; "fused": qkv and ffn.0 (+ GELU in the hipBLASLt epilogue) stay on the
+# library (round 2's default); "fused-ffn2": ffn.2 as well; "lib": everything on hipBLASLt.  Measurements: DESIGN.md §5.
+GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "all")
 FP8_FOLD = os.environ.get("FAIRYGEN_FP8_FOLD", "1") != "0"      # fp8 mode: norm kernels emit (e4m3 rows, scales) directly
+FP8_GEMM = os.environ.get("FAIRYGEN_FP8_GEMM", "own")           # fp8 mode: "own" = fg_gemm_fp8_bf16, "lib" = torch._scaled_mm (hipBLASLt)
 
 
 def own_gemm_ok(rows, n, k):
-    """Shapes the persistent kernel takes AND fills the chip with: 256-column tiles, at least two rounds of the 256 CUs."""
-    return GEMM_BACKEND != "lib" and n % 256 == 0 and k % 128 == 0 and ((rows + 255) // 256) * (n // 256) >= 512
+    """Shapes the persistent kernel takes: 256-column tiles, 128-byte k-steps in pairs, and enough tiles to be worth a 256-workgroup
+    launch.  Round 2 asked for two rounds of the CUs (512 tiles); measured at the 8- / 4- / 2-rank shard sizes (3 410 / 6 820 / 13 640
+    rows) the kernel is within 5 % of the library on every shape with one round or less, 1.6x faster on ffn.2 (K = 14 336:
+    1 154 vs 739 TFLOP/s at 3 410 rows), and the fused residual store replaces a separate pass."""
+    return GEMM_BACKEND != "lib" and n % 256 == 0 and k % 128 == 0 and ((rows + 255) // 256) * (n // 256) >= 64
 
 
 def gemm_bias_own(x, weight, bias):
     return hip.gemm_epilogue(x, weight, bias)
+
+
+def gemm_bias_gelu_own(x, weight, bias):
+    """ffn.0 + nn.GELU(approximate='tanh') (models/wan_video_dit.py:208): GELU on the bf16-rounded Linear output in the GEMM's store."""
+    return hip.gemm_epilogue(x, weight, bias, act="gelu_tanh")
 
 
 def gemm_residual(x, a, weight, bias, mod=None, gate_idx=None):
@@ -94,8 +100,8 @@ class AttentionModule(nn.Module):
         super().__init__()
         self.num_heads = num_heads
 
-    def forward(self, q, k, v):
-        return hip.attention(q, k, v, self.num_heads)
+    def forward(self, q, k, v, scale=None):
+        return hip.attention(q, k, v, self.num_heads, scale=scale)
 
 
 class SelfAttention(nn.Module):
@@ -197,6 +203,11 @@ class WanModel(nn.Module):
         # rotation costs 43 us of VALU per call on a 77 us HBM-bound kernel; < 0.2 % of the outputs move, by 1 bf16 ulp).
         # "f64": the reference's arithmetic exactly (rope_apply upcasts to complex128).
         self.rope_mode = "f32"
+        # True (with rope_mode "f32" and the stock AttentionModule): self-attention's 1/sqrt(d) * log2(e) = 2^-3 * 1.0201 is split — the
+        # 1.0201 goes into q's fp32 RoPE table (q is rounded to bf16 once, as before, from a value 2 % larger), attention is called with
+        # scale' = 2^-3 / log2(e), for which the kernel's pre-multiplied form (64 VALU operations fewer per tile and wave, -4 % time) is
+        # exact.  False: q as the reference rounds it, the kernel's plain form.
+        self.fold_attn_scale = True
         # True: GELU(tanh) applied to the fp32 accumulator in the hipBLASLt epilogue of ffn.0 (one pass less over the
         # (n, ffn) tensor, -1.9 % per forward; verified to be the tanh form, tools/gelu_epilogue_check.py; <= 1 bf16 ulp
         # from the reference's "round, then GELU" order).  False: GEMM, then fg_act_bf16 on the rounded output.
@@ -228,7 +239,7 @@ class WanModel(nn.Module):
     def enable_fp8_linear(self, dtype=torch.float8_e4m3fn):
         """Run the ten Linears of every DiT block like AutoWrappedLinear.fp8_linear when its computation_dtype is fp8:
         per-row dynamic activation scale (fg_fp8_quant_rows_bf16), weights cast to e4m3 with unit scale, bf16 bias,
-        torch._scaled_mm (hipBLASLt fp8 MFMA) with bf16 output.  dtype None switches back to bf16 GEMMs.  The small
+        the row-scaled e4m3 matmul with bf16 output on fg_gemm_fp8_bf16 (or torch._scaled_mm: FAIRYGEN_FP8_GEMM=lib).  dtype None switches back to bf16 GEMMs.  The small
         embedding / head Linears (< 1 % of the FLOPs) stay bf16.  gfx950's fp8 GEMM takes the OCP format only, so
         torch.float8_e4m3fnuz (the MI300-era flavour the reference also accepts) is refused."""
         if dtype is not None and dtype != torch.float8_e4m3fn:
@@ -239,8 +250,11 @@ class WanModel(nn.Module):
         return self
 
     def _scaled_linear(self, xq, scale_a, w8, bias):
-        """torch._scaled_mm exactly as fp8_linear calls it (:347-354): row-wise scale_a, unit scale_b, bf16 bias."""
+        """fp8_linear's matmul (:347-354: torch._scaled_mm with row-wise scale_a, unit scale_b, bf16 bias, bf16 out): on this repo's e4m3
+        MFMA kernel (fg_gemm_fp8_bf16), or — FAIRYGEN_FP8_GEMM=lib, and for shapes the kernel does not take — the library call itself."""
         n = w8.shape[0]
+        if FP8_GEMM == "own" and n % 256 == 0 and xq.shape[1] % 256 == 0:
+            return hip.gemm_fp8(xq, scale_a, w8, bias, lead_shape=(1, xq.shape[0]))
         key = (n, xq.device)
         if key not in self._ones:
             self._ones[key] = torch.ones((1, n), dtype=torch.float32, device=xq.device)
@@ -276,8 +290,10 @@ class WanModel(nn.Module):
     # ------------------------------------------------------------------ host-side tables
     def rope_tables(self, f, h, w, device):
         """(cos, sin) of the per-token complex table, tokens frame-major (pipelines/wan_video.py:1271-1275): two fp64
-        (N, 64) tensors in rope_mode "f64", (one interleaved fp32 (N, 64, 2) tensor, None) in rope_mode "f32"."""
-        key = (f, h, w, str(device), self.rope_mode)
+        (N, 64) tensors in rope_mode "f64"; in rope_mode "f32" two interleaved fp32 (N, 64, 2) tensors {cos, sin}: the table for k and
+        the table for q (the same one, or multiplied by the folded softmax-scale factor: attn_scale())."""
+        fold = self.attn_scale()[1]
+        key = (f, h, w, str(device), self.rope_mode, fold)
         if key not in self._rope_cache:
             tab = torch.cat([
                 self.freqs[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
@@ -285,10 +301,18 @@ class WanModel(nn.Module):
                 self.freqs[2][:w].view(1, 1, w, -1).expand(f, h, w, -1),
             ], dim=-1).reshape(f * h * w, -1)
             if self.rope_mode == "f32":
-                self._rope_cache = {key: (torch.stack([tab.real, tab.imag], dim=-1).to(torch.float32).contiguous().to(device), None)}
+                cs = torch.stack([tab.real, tab.imag], dim=-1)
+                cs_k = cs.to(torch.float32).contiguous().to(device)
+                self._rope_cache = {key: (cs_k, cs_k if fold == 1.0 else (cs * fold).to(torch.float32).contiguous().to(device))}
             else:
                 self._rope_cache = {key: (tab.real.contiguous().to(device), tab.imag.contiguous().to(device))}
         return self._rope_cache[key]
+
+    def attn_scale(self):
+        """(scale passed to self-attention or None for 1/sqrt(d), factor folded into q's RoPE table)."""
+        if self.fold_attn_scale and self.rope_mode == "f32" and all(type(b.self_attn.attn) is AttentionModule for b in self.blocks):
+            return hip.pow2_softmax_scale(self.dim // self.num_heads)
+        return None, 1.0
 
     def patchify(self, x):
         """Conv3d with kernel == stride == (1,p,p) is a GEMM over unfolded patches; returns frame-major
@@ -320,7 +344,7 @@ class WanModel(nn.Module):
         sa = blk.self_attn
         if fp8 is not None:
             qkv = lin(h, 0, bqkv)
-        elif GEMM_BACKEND == "all" and own and own_gemm_ok(h.shape[1], 3 * c, c):
+        elif GEMM_BACKEND == "all" and own_gemm_ok(h.shape[1], 3 * c, c):      # a plain Linear: hot adapters add to its output below
             qkv = gemm_bias_own(h, wqkv, bqkv)
         else:
             qkv = gemm_bias(h, wqkv, bqkv)
@@ -328,10 +352,13 @@ class WanModel(nn.Module):
             for j, nm in enumerate(("q", "k", "v")):
                 self._hot(f"blocks.{i}.self_attn.{nm}", h, qkv[..., j * c:(j + 1) * c])
         v = qkv[..., 2 * c:]
+        # rope tables per operand: fp64 (cos, sin) for both, or the fp32 interleaved tables of k and q (rope_tables)
+        rk, rq = ((cos, None), (sin, None)) if cos.dtype == torch.float32 else ((cos, sin), (cos, sin))
+        scale = self.attn_scale()[0]      # None (1/sqrt(d)), or the power-of-two form that goes with the pre-multiplied q table
         if not sharded:
-            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
-            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
-            a = sa.attn(q, k, v)
+            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, *rk)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, *rq)
+            a = sa.attn(q, k, v) if scale is None else sa.attn(q, k, v, scale=scale)
         elif shard.attn_mode == "ulysses":
             # token shard -> head shard (all N tokens of 24/P heads), attention, head shard -> token shard.  The
             # norm+RoPE kernels and one strided copy write q | k | v straight into the all-to-all send buffer.
@@ -339,25 +366,25 @@ class WanModel(nn.Module):
             g = c // nh * shard.heads_local(nh)
             send = shard.ulysses_send_buffer(shard_total, c, qkv, n_loc)           # (P, chunk, 3, g)
             flat, layout = send.view(-1), (g, size * 3 * g, 3 * g)
-            hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin, grouped=(flat, *layout))
-            hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin, grouped=(flat[g:], *layout))
+            hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, *rq, grouped=(flat, *layout))
+            hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, *rk, grouped=(flat[g:], *layout))
             hip.copy_groups(qkv.view(-1)[2 * c:], g, 3 * c, flat[2 * g:], size * 3 * g, 3 * g, p_, n_loc, g)
             pending = shard.ulysses_exchange_async(send, shard_total)
             yield i
             qg, kg, vg = pending.wait()
             o_full = shard.ulysses_out_buffer(shard_total, g, qkv)
-            hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0))
+            hip.attention(qg, kg, vg, shard.heads_local(nh), out=o_full[:shard_total].unsqueeze(0), scale=scale)
             pending = shard.ulysses_out_async(o_full, shard_total, n_loc)
             yield i
             a = torch.empty((1, n_loc, c), dtype=qkv.dtype, device=qkv.device)
             hip.copy_groups(pending.wait_blocks().view(-1), size * g, g, a.view(-1), g, c, p_, n_loc, g)
         else:
-            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, cos, sin)
+            k = hip.rmsnorm_rope(qkv[..., c:2 * c], sa.norm_k.weight, nh, eps, *rk)
             pending = shard.all_gather_kv_async(k, v, shard_total)
-            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, cos, sin)
+            q = hip.rmsnorm_rope(qkv[..., :c], sa.norm_q.weight, nh, eps, *rq)
             yield i
             k, v = pending.wait()
-            a = sa.attn(q, k, v)
+            a = sa.attn(q, k, v) if scale is None else sa.attn(q, k, v, scale=scale)
         # x += gate_msa*y ; h = norm3(x)  (reference :225-226)
         if own and own_gemm_ok(a.shape[1], c, c):      # the gated add happens in the GEMM's store
             x = gemm_residual(x, a, sa.o.weight, sa.o.bias, mod, 2)
@@ -486,6 +513,8 @@ class WanModel(nn.Module):
                 f = None
             elif hot and f"blocks.{i}.ffn.0" in self.hot_loras:      # the adapter adds to the pre-activation: no epilogue fusion
                 f = hip.activation(self._hot(f"blocks.{i}.ffn.0", h, gemm_bias(h, blk.ffn[0].weight, blk.ffn[0].bias)), "gelu_tanh")
+            elif GEMM_BACKEND == "all" and own_gemm_ok(h.shape[1], blk.ffn[0].weight.shape[0], c):      # GELU(tanh) in the own GEMM's store
+                f = gemm_bias_gelu_own(h, blk.ffn[0].weight, blk.ffn[0].bias)
             elif self.gelu_epilogue:      # GELU(tanh) in the hipBLASLt epilogue: one pass less over the (n, ffn) tensor
                 f = gemm_bias_gelu(h, blk.ffn[0].weight, blk.ffn[0].bias)
             else:

@@ -34,7 +34,7 @@ extern "C" {
 
 typedef void* fg_stream_t;   /* hipStream_t */
 
-int         fg_version(void);            /* ABI version, currently 2 */
+int         fg_version(void);            /* ABI version, currently 3 */
 const char* fg_last_error(void);         /* thread-local, valid until the next failing call */
 
 /* ------------------------------------------------------------------ DiT token-side kernels (HBM-bound)
@@ -82,28 +82,34 @@ int fg_residual_ln_fp8_bf16(const void* x, const void* y, const void* gate, void
                             int64_t mod_rows, int64_t first_rows, int64_t mod_ld, float fp8_max, fg_stream_t stream);
 
 /* nn.Linear of the DiT blocks (models/wan_video_dit.py:130-133,156-159,208-209): c[M,N] = a[M,K] w[N,K]^T + bias[N], bf16 in and
- * out, fp32 accumulation, bias added to the accumulator before the one bf16 rounding (as the library GEMM does).  a has leading
- * dimension lda, c ldc (elements); w is the row-major (out_features, in_features) weight; N %% 256 == 0, K %% 64 == 0.
- * flags: reserved (0).  Hand-scheduled 256x256x64 MFMA kernel (csrc/gen_gemm_w4.py). */
-int fg_gemm_bias_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
-                      int64_t M, int64_t N, int64_t K, int flags, fg_stream_t stream);
-
-/* The same Linear with the DiT block's residual folded into the store (models/wan_video_dit.py:188-193 GateModule, :225-228):
+ * out, fp32 accumulation, bias added to the accumulator before the bf16 rounding — alone or with the op that follows it in the block
+ * folded into the store (:188-193 GateModule, :208 nn.GELU(approximate='tanh'), :225-228):
  *   mode 0: c = bf16(acc + bias)                                   (nn.Linear)
  *   mode 2: c = bf16(c + bf16(gate * bf16(acc + bias)))            (x = x + gate * Linear(.), x read in place from c)
  *   mode 3: c = bf16(c + bf16(acc + bias))                         (x = x + Linear(.))
- * with the bf16 rounding points of the reference's three separate ops.  gate: a table of gate_rows (1 or 2) rows of N values, row
- * stride gate_ld elements; with 2 rows, output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the
- * others row 1.  N %% 256 == 0 or N %% 192 == 0, K %% 128 == 0.  Persistent kernel: one workgroup per CU walks a list of
- * 256 x 256 (N %% 256 == 0) or 256 x 192 output tiles (csrc/gen_gemm_p.py).  The tiles left over after the last whole round of the
- * 256 CUs are finished as pieces: with `workspace` (fg_gemm_workspace_bytes(M, N, K) bytes of device memory, 16-byte aligned; may
- * be NULL) cut along K into fp32 partial sums that a second small kernel adds in k order before the same epilogue — those
- * elements' fp32 summation is then grouped per piece (fixed for a given shape; every other element is one full-K accumulation in
- * k order); without it, cut into 64-column pieces, every element accumulated in k order. */
+ *   mode 4: c = bf16(gelu_tanh(bf16(acc + bias)))                  (ffn.0 + GELU)
+ * with the bf16 rounding points of the reference's separate ops.  a has leading dimension lda, c ldc (elements); w is the row-major
+ * (out_features, in_features) weight.  gate: a table of gate_rows (1 or 2) rows of N values, row stride gate_ld elements; with 2 rows,
+ * output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the others row 1.  N %% 256 == 0, K %% 128 == 0.
+ * Persistent kernel: one workgroup per CU of the device walks a list of 256 x 256 output tiles (csrc/gen_gemm_p.py).  The tiles left
+ * over after the last whole round of the CUs are finished as pieces: with `workspace` (fg_gemm_workspace_bytes(M, N, K) bytes of
+ * device memory, 16-byte aligned; may be NULL) and K >= 6144 cut along K into fp32 partial sums that a second small kernel adds in k
+ * order before the same epilogue — those elements' fp32 summation is then grouped per piece (fixed for a given shape and device; every
+ * other element is one full-K accumulation in k order); otherwise cut into 64-column pieces, every element accumulated in k order. */
 int64_t fg_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int fg_gemm_epilogue_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
                           int64_t first_rows, void* workspace, fg_stream_t stream);
+
+/* The matmul of AutoWrappedLinear.fp8_linear (core/vram/layers.py:343-357: torch._scaled_mm(x_fp8, w_fp8.T, scale_a (rows, 1),
+ * scale_b = ones (1, out), bias, out_dtype = bf16)) on the same persistent kernel with e4m3 operands (OCP float8_e4m3fn,
+ * v_mfma_f32_32x32x64_f8f6f4): y = bf16((acc * scale_a[row]) + bias[col]) — one fp32 rounding per operation, as the library op —
+ * followed by the epilogue `mode` of fg_gemm_epilogue_bf16 (0, 2, 3, 4) on y.  a_fp8: (M, K) bytes with leading dimension lda,
+ * w_fp8: (N, K) row-major, scale_a: M fp32 values (fg_fp8_quant_rows_bf16 / the fp8-output norm kernels produce a_fp8 and scale_a).
+ * N %% 256 == 0, K %% 256 == 0, lda %% 16 == 0; workspace as above (taken for K >= 12288). */
+int fg_gemm_fp8_bf16(const void* a_fp8, int64_t lda, const float* scale_a, const void* w_fp8, const void* bias, void* c, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
+                     int64_t first_rows, void* workspace, fg_stream_t stream);
 
 /* RMSNorm over the full row (all heads), * weight, then optional 3-D RoPE on adjacent pairs:
  * RMSNorm.forward models/wan_video_dit.py:99-110 + rope_apply :91-96 (SelfAttention.forward :140-144,

@@ -82,9 +82,10 @@ def section_serving(R):
     z0 = seeded((1, 48, 1, 8, 8), 4)
     fn = ref_pipe.model_fn_wan_video
     steps, thresh, model_id = 8, 25.0, "Wan2.1-I2V-14B-720P"      # synthetic weights: rescaled distances 8-21 per step -> a mix of skipped and computed steps
+    thresh_t2v_skip = 100.0      # T2V mode: rescaled distances 42-96 per step, so 25 skips nothing there; 100 skips steps 1, 2 and 4
     out = {}
-    for mode, fuse in (("ti2v", True), ("t2v", False)):
-        tea = [ref_pipe.TeaCache(steps, rel_l1_thresh=thresh, model_id=model_id) for _ in range(2)]
+    for mode, fuse, thr in (("ti2v", True, thresh), ("t2v", False, thresh), ("t2v_skip", False, thresh_t2v_skip)):
+        tea = [ref_pipe.TeaCache(steps, rel_l1_thresh=thr, model_id=model_id) for _ in range(2)]
         sched = R["sched"]("Wan")
         sched.set_timesteps(steps, denoising_strength=1.0, shift=5.0)
         latents = lat.clone()
@@ -129,7 +130,7 @@ def section_serving(R):
     save("serving.safetensors", out, {
         "config": str(kw), "weights": "synthetic.random_state_dict(dit_shapes(TINY_DIT_KWARGS), seed=1234)",
         "inputs": f"as dit_tiny.safetensors; {steps} steps cfg 5 shift 5; TeaCache(rel_l1_thresh={thresh}, model_id={model_id!r}) per CFG branch; "
-                  "t2v: fuse_vae_embedding_in_latents=False (no first-frame pin); sliding window: latents=seeded((1,48,7,8,8),98) t=bf16(700) ctx+ size 4 stride 2; hot LoRA: x=seeded((1,40,256),91) w=seed 92 x0.05 (384,256) "
+                  f"t2v: fuse_vae_embedding_in_latents=False (no first-frame pin); t2v_skip: the same with rel_l1_thresh={thresh_t2v_skip}; sliding window: latents=seeded((1,48,7,8,8),98) t=bf16(700) ctx+ size 4 stride 2; hot LoRA: x=seeded((1,40,256),91) w=seed 92 x0.05 (384,256) "
                   "b=seed 93 x0.1; adapters (A1 seed 94 (4,256), B1 seed 95, alpha 0.5), (A2 seed 96 (8,256), B2 seed 97, alpha 2), all x0.05",
         "source": "diffsynth/pipelines/wan_video.py TeaCache :1016-1065, model_fn_wan_video :1297-1300,1316-1317,1375-1376; "
                   "core/vram/layers.py AutoWrappedLinear.lora_forward :417-428; base_pipeline.py:249-262; TemporalTiler_BCTHW :1069-1118"})

@@ -100,7 +100,6 @@ def test_fused_residual_norms(hip):
 
 @pytest.mark.parametrize("M,K,N", [(700, 256, 768),       # 9 tiles: every one a 64-column tail piece (second body, ring of 3)
                                    (4200, 512, 4096),     # 272 tiles: one full round of 256-column tiles + cut tail, ragged last rows
-                                   (600, 384, 576),       # 192-column tiles (N % 256 != 0)
                                    (10500, 128, 2048)])   # 336 tiles: left-over tiles NOT cut (10 per XCD), K = one step pair, 4 rows in the last row tile
 def test_gemm_epilogue(hip, M, K, N):
     """fg_gemm_epilogue_bf16 (persistent MFMA GEMM, nn.Linear of the DiT blocks: models/wan_video_dit.py:130-133,208-209): error to
@@ -124,6 +123,16 @@ def test_gemm_epilogue(hip, M, K, N):
     assert torch.equal(got.cpu(), res + table[0, 2] * y.cpu())
     got = hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True)
     assert torch.equal(got.cpu(), res + y.cpu())
+    # mode 4: nn.Linear then nn.GELU(approximate='tanh') (:208): GELU of the kernel's own bf16 y, rounded again; exp2 / rcp based like
+    # fg_act_bf16: <= 1 bf16 ulp from libm's, nearly all elements identical
+    got = hip.gemm_epilogue(dev(x), dev(w), dev(b), act="gelu_tanh")
+    assert_close_bf16(got, F.gelu(y.cpu(), approximate="tanh"), 1.0, "gemm + gelu", max_mismatch=0.05)
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True, act="gelu_tanh")
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_epilogue(dev(x), dev(w), dev(b), out=torch.empty((M, N - 8), dtype=torch.bfloat16, device="cuda"))      # wrong-sized out
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_epilogue(dev(x), dev(w[:576]), dev(b[:576]))                         # N % 256 != 0
     # strided input rows (a column slice of a wider tensor), as the fused QKV output is consumed elsewhere
     wide = seeded((1, M, K + 64), 46)
     y2 = hip.gemm_epilogue(dev(wide)[..., :K], dev(w), dev(b))
@@ -132,6 +141,89 @@ def test_gemm_epilogue(hip, M, K, N):
         hip.gemm_epilogue(dev(x), dev(w)[:, : K - 64].contiguous(), dev(b))          # K mismatch
     with pytest.raises(hip.HipLibraryError):
         hip.gemm_epilogue(x, w, b)                                                   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("M,K,N", [(4200, 6144, 4096),     # 272 tiles: one full round + 2 left-over tiles per XCD, k-split 16 ways; 104 rows in the last row tile
+                                   (600, 14336, 3072),     # ffn.2's reduction length: 36 tiles = 4-5 per XCD, no full round, cut 8 / 6 ways
+                                   (8300, 14336, 512),     # 66 tiles: 8-9 per XCD on 32 CUs, cut 4 / 3 ways (224 k-steps -> 75 + 75 + 74)
+                                   (66200, 6144, 256)])    # 259 tiles in one column: one left-over tile (32 pieces) on three XCDs, none on the others
+def test_gemm_epilogue_ksplit(hip, M, K, N):
+    """The k-split path of fg_gemm_epilogue_bf16 (K >= 6 144 with a workspace: the left-over tiles of an XCD's last round are computed as
+    k-range pieces whose fp32 accumulators go to the workspace and are added in k order by gemm_reduce_kernel, csrc/dit_gemm.hip) — the
+    default path of ffn.2 (models/wan_video_dit.py:208-209,225-228).  Checked (1) against the fp32 product on sampled rows with the 2x
+    criterion, (2) against the same kernel without a workspace (every element one k-ordered accumulation): <= 1 bf16 ulp apart, (3) the
+    residual modes: x + gate * y with the reference's two roundings from the kernel's OWN k-split y, bit for bit (the reduce kernel
+    re-implements the accumulator lane map, the gate row select and the epilogue)."""
+    x, w, b = seeded((1, M, K), 141, scale=0.5), seeded((N, K), 142, scale=0.02), seeded((N,), 143, scale=0.2)
+    dx, dw, db = dev(x), dev(w), dev(b)
+    y = hip.gemm_epilogue(dx, dw, db)
+    y_nows = hip.gemm_epilogue(dx, dw, db, workspace=False)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 100), torch.arange(M - 300, M)])
+    ref32 = F.linear(x[0, rows].float(), w.float(), b.float())
+    ref16 = F.linear(x[0, rows], w, b).float()
+    ref_err = (ref16 - ref32).abs().max().item()
+    for name, t in (("k-split", y), ("no workspace", y_nows)):
+        err = (t[0].cpu()[rows].float() - ref32).abs().max().item()
+        assert err <= 2 * ref_err + 1e-3, f"gemm {M}x{K}x{N} ({name}): {err} vs reference bf16 error {ref_err}"
+    assert_close_bf16(y, y_nows, 1.0, "k-split vs single accumulation", max_mismatch=0.02)
+    assert not torch.equal(y, y_nows), "the k-split path did not run (identical to the single-accumulation result)"
+    res = seeded((1, M, N), 144)
+    first = M - 300                                            # the gate class changes inside the last rows (left-over tiles live there)
+    table = seeded((2, 6, N), 145)
+    idx = (torch.arange(M) >= first).long()
+    got = hip.gemm_epilogue(dx, dw, db, out=dev(res).clone(), residual=True, mod=hip.ModTable(dev(table), first), gate_idx=5)
+    assert torch.equal(got.cpu(), res + table[idx, 5].unsqueeze(0) * y.cpu())
+    got = hip.gemm_epilogue(dx, dw, db, out=dev(res).clone(), residual=True, mod=hip.ModTable(dev(table), 130), gate_idx=2)
+    assert torch.equal(got.cpu(), res + table[(torch.arange(M) >= 130).long(), 2].unsqueeze(0) * y.cpu())
+    got = hip.gemm_epilogue(dx, dw, db, out=dev(res).clone(), residual=True)
+    assert torch.equal(got.cpu(), res + y.cpu())
+    # strided A rows through the k-split path
+    wide = seeded((1, 600, K + 128), 146, scale=0.5)
+    dwide = dev(wide)
+    assert torch.equal(hip.gemm_epilogue(dwide[..., 64:64 + K], dw, db), hip.gemm_epilogue(dwide[..., 64:64 + K].contiguous(), dw, db))
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 3072, 768),        # 9 tiles: 64-column pieces (second body); 24 k-steps of 128 e4m3
+                                   (4200, 1024, 4096),      # 272 tiles: a full round + cut tail, ragged last rows, 8 k-steps
+                                   (600, 14336, 3072)])     # ffn.2's reduction: 112 k-steps, left-over tiles as k-range pieces + reduce kernel
+def test_gemm_fp8(hip, M, K, N):
+    """fg_gemm_fp8_bf16 = the torch._scaled_mm call of AutoWrappedLinear.fp8_linear (core/vram/layers.py:343-357) on e4m3 MFMA:
+    (a) against the oracle's written-out op (oracle.wan_dit.scaled_mm; pinned by the reference-run 1x1 vectors) on the same fp8 operands:
+    e4m3 x e4m3 products are exact in fp32, so only the fp32 summation order differs: <= 1 bf16 ulp, nearly all elements identical;
+    (b) against the library op on the device, same criterion; (c) residual / GELU epilogues from the kernel's own y, bit for bit."""
+    x = seeded((1, M, K), 151, scale=2.0)
+    x[0, 5] *= 300.0                                          # rows above the fp8 range: scale_a > 1
+    x[0, M - 3] *= 1000.0
+    w, b = seeded((N, K), 152, scale=0.05), seeded((N,), 153, scale=0.3)
+    xq, sc = hip.fp8_quant_rows(dev(x))
+    assert sc[5].item() > 1.0 and sc[0].item() == 1.0
+    w8 = dev(w).to(torch.float8_e4m3fn)
+    y = hip.gemm_fp8(xq, sc, w8, dev(b))
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    rows = torch.cat([torch.arange(0, 160), torch.arange(M - 160, M)])
+    want = wan_dit.scaled_mm(xq[rows].cpu(), w8.cpu().T, sc[rows].cpu(), torch.ones((1, N)), b, torch.bfloat16)
+    assert_close_bf16(y[rows], want, 1.0, "fp8 gemm vs oracle", max_mismatch=0.02)
+    lib = torch._scaled_mm(xq, w8.T, scale_a=sc, scale_b=torch.ones((1, N), device="cuda"), bias=dev(b), out_dtype=torch.bfloat16)
+    assert_close_bf16(y, lib, 1.0, "fp8 gemm vs torch._scaled_mm", max_mismatch=0.02)
+    if K >= 12288:
+        y_nows = hip.gemm_fp8(xq, sc, w8, dev(b), workspace=False)
+        assert_close_bf16(y, y_nows, 1.0, "k-split vs single accumulation", max_mismatch=0.02)
+        assert not torch.equal(y, y_nows), "the k-split path did not run"
+    res = seeded((M, N), 154)
+    first = M - 200
+    table = seeded((2, 6, N), 155)
+    idx = (torch.arange(M) >= first).long()
+    got = hip.gemm_fp8(xq, sc, w8, dev(b), out=dev(res).clone(), residual=True, mod=hip.ModTable(dev(table), first), gate_idx=5)
+    assert torch.equal(got.cpu(), res + table[idx, 5] * y.cpu())
+    got = hip.gemm_fp8(xq, sc, w8, dev(b), out=dev(res).clone(), residual=True)
+    assert torch.equal(got.cpu(), res + y.cpu())
+    got = hip.gemm_fp8(xq, sc, w8, dev(b), act="gelu_tanh", lead_shape=(1, M))
+    assert got.shape == (1, M, N)
+    assert_close_bf16(got[0], F.gelu(y.cpu(), approximate="tanh"), 1.0, "fp8 gemm + gelu", max_mismatch=0.05)
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_fp8(xq, sc[:-1], w8, dev(b))
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm_fp8(xq.cpu(), sc.cpu(), w8.cpu(), b)          # CPU tensors: no fallback
 
 
 @pytest.mark.parametrize("heads,C,grid", [(24, 3072, (2, 3, 5)), (2, 256, (3, 4, 4))])
@@ -295,6 +387,69 @@ def test_attention_split_kv(hip, nq, nkv, heads, mode):
 def test_attention_peaked_softmax(hip):
     # large-magnitude queries: near one-hot softmax rows exercise the running-max rescale path
     _attn_case(hip, 200, 333, 2, 30, scale_q=8.0)
+
+
+def _spiked_keys(q, k, nkv, picks):
+    """Key rows aligned with a few query rows at growing magnitude, late in the sequence: the running max of those rows (every head)
+    jumps by ~15-40 log2 units at those tiles, far beyond the kernels' deferred-rescale threshold of 2^6 (tools/attn_ab.py --spike)."""
+    k = k.clone()
+    for i, (pos, row) in enumerate(picks):
+        k[0, pos] = (q[0, row].float() * (1.5 + i)).to(torch.bfloat16)
+    return k
+
+
+@pytest.mark.parametrize("form", ["plain", "pow2"])
+@pytest.mark.parametrize("nq,nkv,heads,scale_q", [(300, 1500, 2, 1.0),        # one q-block + a ragged one; 1500 = 23 tiles + 28 keys
+                                                   (300, 1500, 2, 8.0),        # peaked rows AND spikes
+                                                   (700, 2700, 24, 8.0)])      # every q-block cut into KV ranges (split-KV + merge)
+def test_attention_w4_deferred_rescale(hip, nq, nkv, heads, scale_q, form):
+    """attn_fwd_w4_kernel (the self-attention kernel: Nkv > 1024, csrc/attention.hip dispatch) on inputs whose running max moves by
+    more than 2^6 between tiles, so its out-of-line rescale block (O, l and the pending score tile rescaled once) executes — in the
+    first tiles, mid-sequence, in the last full tile and in the ragged last tile.  flash_attention of models/wan_video_dit.py:54-59;
+    criterion: error to the oracle's fp32 result <= 2x the error of the oracle's own bf16 result + floor.
+    Both bodies of the kernel: "plain" (scale = 1/sqrt(d): exponent argument by v_fma on the fp32 scores) and "pow2" (the scale the
+    pipeline passes for self-attention, scale * log2(e) = 2^-3: Q^T pre-multiplied exactly, -max as the MFMA's C operand)."""
+    c = heads * 128
+    scale, fold = (None, 1.0) if form == "plain" else hip.pow2_softmax_scale(128)
+    assert form == "plain" or abs(scale * 1.4426950408889634 - 0.125) < 1e-9
+    q, k, v = seeded((1, nq, c), 130, scale=scale_q), seeded((1, nkv, c), 131), seeded((1, nkv, c), 132)
+    last_full = (nkv // 64) * 64 - 3
+    k = _spiked_keys(q, k, nkv, [(70, 5), (nkv // 3, 17), (nkv // 2, 150), (last_full, 255), (nkv - 2, 299), (nkv - 1, 5)])
+    if heads == 24:
+        import ctypes
+        R, S = ctypes.c_int(), ctypes.c_int()
+        lib = hip.load()
+        assert lib.fg_attn_split_choice(1, nq, nkv, heads, lib.fg_attn_workspace_bytes(1, nq, nkv, heads), ctypes.byref(R), ctypes.byref(S)) == 0
+        assert S.value > 1, "this shape is meant to take the split-KV path"
+    # softmax(scale q k^T) = softmax((q / fold) k^T / sqrt(d)): the fp32 reference of the pow2 form is the oracle on q / fold (fp32);
+    # the yardstick is the error of the oracle's own bf16 op on the same (equally peaked) problem
+    ref32 = wan_dit.attention(q.float() / fold, k.float(), v.float(), heads)
+    ref16 = wan_dit.attention(q, k, v, heads).float()
+    got = hip.attention(dev(q), dev(k), dev(v), heads, scale=scale).float().cpu()
+    assert torch.isfinite(got).all()
+    err_ref = (ref16 - wan_dit.attention(q.float(), k.float(), v.float(), heads)).abs().max().item()
+    err = (got - ref32).abs().max().item()
+    assert err <= 2 * err_ref + 2e-3, f"w4 attention ({form}), spiked keys: err {err} vs reference-bf16 err {err_ref}"
+    # the spiked rows themselves are near one-hot on their key: check them separately so that a wrong rescale cannot hide in a max
+    for row in (5, 17, 150, 255, 299):
+        e = (got[0, row] - ref32[0, row]).abs().max().item()
+        assert e <= 2 * err_ref + 2e-3, f"row {row}: {e}"
+
+
+def test_attention_w4_strided_qkv(hip):
+    """The production layout of self-attention: q, k, v are the three column slices of ONE (N, 3C) GEMM output (ld = 3C), Nkv > 1024 so
+    the w4 kernel runs; must equal the call on contiguous copies bit for bit, and satisfy the oracle criterion."""
+    heads, n = 2, 1337
+    c = heads * 128
+    qkv = seeded((1, n, 3 * c), 140)
+    d = dev(qkv)
+    got = hip.attention(d[..., :c], d[..., c:2 * c], d[..., 2 * c:], heads)
+    same = hip.attention(d[..., :c].contiguous(), d[..., c:2 * c].contiguous(), d[..., 2 * c:].contiguous(), heads)
+    assert torch.equal(got, same)
+    q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    ref32 = wan_dit.attention(q.float(), k.float(), v.float(), heads)
+    err_ref = (wan_dit.attention(q, k, v, heads).float() - ref32).abs().max().item()
+    assert (got.float().cpu() - ref32).abs().max().item() <= 2 * err_ref + 2e-3
 
 
 def test_attention_strided_inputs(hip):

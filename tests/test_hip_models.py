@@ -94,14 +94,15 @@ def test_teacache_loop_vs_golden(tiny_dit, golden):
     g = golden("serving.safetensors")
     m, sd, cfg = tiny_dit
     lat, ctx_p, ctx_n, z0, _ = _tiny_inputs()
-    for mode, first in (("ti2v", z0), ("t2v", None)):
+    assert g["t2v_skip_skipped"].sum().item() >= 4      # the T2V-mode golden with skipped steps (threshold 100): steps 1, 2, 4 of both branches
+    for mode, first, thresh in (("ti2v", z0, 25.0), ("t2v", None, 25.0), ("t2v_skip", None, 100.0)):
         pipe = WanVideoPipeline(device="cuda", torch_dtype=torch.bfloat16)
         pipe.dit = m
         pipe.scheduler.set_timesteps(8, denoising_strength=1.0, shift=5.0)
         latents = lat.clone()
         if first is not None:
             latents[:, :, 0:1] = first
-        tea = [TeaCache(8, rel_l1_thresh=25.0, model_id="Wan2.1-I2V-14B-720P") for _ in range(2)]
+        tea = [TeaCache(8, rel_l1_thresh=thresh, model_id="Wan2.1-I2V-14B-720P") for _ in range(2)]
         skipped = []
         orig = TeaCache.check
 
@@ -223,14 +224,23 @@ def test_fp8_linear_mode_vs_oracle(tiny_dit):
     scale_a = torch.clamp(x2.abs().amax(-1, keepdim=True) / 448.0, min=1.0).float()
     ref = torch._scaled_mm((x2 / (scale_a + 1e-8)).to(torch.float8_e4m3fn), w.to(torch.float8_e4m3fn).T, scale_a=scale_a,
                            scale_b=torch.ones((1, 1024), device="cuda"), bias=b, out_dtype=torch.bfloat16)
-    got = m._scaled_linear(*fh.fp8_quant_rows(x), w.to(torch.float8_e4m3fn), b)[0]
-    assert torch.equal(got, ref)
+    got = m._scaled_linear(*fh.fp8_quant_rows(x), w.to(torch.float8_e4m3fn), b)[0]      # fg_gemm_fp8_bf16 (the default) ...
+    from fairygen_amd import wan_video_dit as wd
+    saved, wd.FP8_GEMM = wd.FP8_GEMM, "lib"
+    try:
+        got_lib = m._scaled_linear(*fh.fp8_quant_rows(x), w.to(torch.float8_e4m3fn), b)[0]      # ... and the library op behind the same seam
+    finally:
+        wd.FP8_GEMM = saved
+    assert torch.equal(got_lib, ref)
+    # e4m3 products are exact in fp32: the own kernel differs from the library only in fp32 summation order
+    assert (got != ref).float().mean().item() < 0.01
+    assert (got.float() - ref.float()).abs().max().item() <= 2.0 ** -7 * ref.float().abs().max().item()
     cpu = wan_dit.fp8_linear(x.cpu(), w.cpu(), b.cpu())[0]
     assert (got.float().cpu() - cpu.float()).abs().max().item() <= 2.0 ** -7 * cpu.float().abs().max().item()
 
 
 def test_fp8_linear_vs_reference_golden(tiny_dit, golden):
-    """The product's fp8 Linear (fg_fp8_quant_rows_bf16 + torch._scaled_mm on the device, WanModel._scaled_linear) against the
+    """The product's fp8 Linear (fg_fp8_quant_rows_bf16 + fg_gemm_fp8_bf16; also the library op it replaced) against the
     outputs of the REFERENCE's own fp8_linear (oracle/gen_fp8_linear_1x1.py: the 1-row x 1-output calls this container's CPU backend
     accepts).  All cases of a reduction length go through ONE call — rows = the cases' activation rows, weight rows = the cases'
     weights — and entry (i, i) is case i (per-row scales: rows do not mix).  fp8 x fp8 products are exact in fp32; only the fp32
@@ -243,10 +253,19 @@ def test_fp8_linear_vs_reference_golden(tiny_dit, golden):
         q, sc = fh.fp8_quant_rows(x.unsqueeze(0))
         ref_sc = torch.clamp(x.float().abs().amax(-1, keepdim=True).to(torch.bfloat16) / 448.0, min=1.0).float()
         assert torch.equal(sc, ref_sc) and (sc > 1).any() and (sc == 1).any()
-        got = torch.diagonal(m._scaled_linear(q, sc, w.to(torch.float8_e4m3fn), b)[0]).float().cpu()
-        err = (got - want.float()).abs()
-        assert (err <= 2.0 ** -7 * want.float().abs().clamp_min(2.0 ** -6)).all(), err.max().item()
-        assert (got == want.float()).float().mean().item() >= 0.9
+        # the own e4m3 kernel (weight rows padded with zeros to its 256-column tile: 64 cases -> N = 256), and the library op
+        cases = w.shape[0]
+        w_pad = torch.zeros((256, k), dtype=torch.bfloat16, device="cuda")
+        w_pad[:cases] = w
+        b_pad = torch.zeros((256,), dtype=torch.bfloat16, device="cuda")
+        b_pad[:cases] = b
+        own = fh.gemm_fp8(q, sc, w_pad.to(torch.float8_e4m3fn), b_pad)[:, :cases]
+        lib = torch._scaled_mm(q, w.to(torch.float8_e4m3fn).T, scale_a=sc, scale_b=torch.ones((1, cases), device="cuda"), bias=b, out_dtype=torch.bfloat16)
+        for name, full in (("fg_gemm_fp8_bf16", own), ("torch._scaled_mm", lib)):
+            got = torch.diagonal(full).float().cpu()
+            err = (got - want.float()).abs()
+            assert (err <= 2.0 ** -7 * want.float().abs().clamp_min(2.0 ** -6)).all(), (name, err.max().item())
+            assert (got == want.float()).float().mean().item() >= 0.9, name
 
 
 def test_medium_dit_block_stack_vs_oracle():

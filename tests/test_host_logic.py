@@ -51,16 +51,24 @@ def test_gemm_entry_point_validation_and_backend_policy():
         p16, K, p16, p16, p16, N, M, N, K, mode, gate, rows, ld, 0, ws, None)
     assert call(512, 250, 256) == -1 and b"N % 256" in lib.fg_last_error()
     assert call(512, 256, 192) == -1 and b"K % 128" in lib.fg_last_error()
+    assert call(512, 576, 384) == -1 and b"N % 256" in lib.fg_last_error()      # the 192-column tiling of round 2 is gone
     assert call(512, 256, 256, mode=1) == -1 and b"mode must be" in lib.fg_last_error()
+    assert call(512, 256, 256, mode=5) == -1 and b"mode must be" in lib.fg_last_error()
     assert call(512, 256, 256, mode=2) == -1 and b"gate table" in lib.fg_last_error()
     assert call(512, 256, 256, ws=ctypes.c_void_p(8)) == -1 and b"workspace" in lib.fg_last_error()
-    assert lib.fg_gemm_workspace_bytes(27280, 3072, 14336) == 256 * 256 * 256 * 4      # one fp32 tile per CU
-    assert lib.fg_gemm_workspace_bytes(600, 576, 384) == 0                             # 192-column tiling: no k-split
-    # the policy: shapes the persistent kernel takes AND fills the chip with (two rounds of 256 CUs of 256 x 256 tiles)
+    assert lib.fg_gemm_workspace_bytes(27280, 3072, 14336) == 256 * 256 * 256 * 4      # one fp32 tile per CU (256 assumed without a device)
+    assert lib.fg_gemm_workspace_bytes(600, 576, 384) == 0
+    # the e4m3 form: same checks, K in 256s, a scale pointer
+    call8 = lambda M, N, K, scale=p16, mode=0: lib.fg_gemm_fp8_bf16(p16, K, scale, p16, p16, p16, N, M, N, K, mode, None, 1, 0, 0, None, None)      # noqa: E731
+    assert call8(512, 256, 384) == -1 and b"K % 256" in lib.fg_last_error()
+    assert call8(512, 256, 512, scale=None) == -1 and b"null pointer" in lib.fg_last_error()
+    assert call8(512, 256, 512, mode=7) == -1 and b"mode must be" in lib.fg_last_error()
+    # the policy: every shape the persistent kernel takes with at least 64 tiles, shard sizes included
     assert wd.GEMM_BACKEND in ("fused", "fused-ffn2", "all", "lib")
     if wd.GEMM_BACKEND != "lib":
         assert wd.own_gemm_ok(27280, 3072, 3072) and wd.own_gemm_ok(13640, 3072, 3072) and wd.own_gemm_ok(27280, 3072, 14336)
-        assert not wd.own_gemm_ok(6820, 3072, 3072)            # a 1/4 token shard: 324 tiles, left to the library's tuned solutions
+        assert wd.own_gemm_ok(6820, 3072, 3072) and wd.own_gemm_ok(3410, 3072, 3072) and wd.own_gemm_ok(3410, 3072, 14336)      # 1/4 and 1/8 token shards
+        assert not wd.own_gemm_ok(320, 256, 256)               # the tiny test models: a handful of tiles, left to the library
         assert not wd.own_gemm_ok(27280, 128, 128) and not wd.own_gemm_ok(27280, 3072, 3000)
 
 

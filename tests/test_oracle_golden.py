@@ -61,10 +61,11 @@ def test_teacache_loop(golden):
     sd = synthetic.random_state_dict(synthetic.dit_shapes(cfg), seed=1234)
     lat, ctx_p, ctx_n, z0, _ = _tiny_inputs()
     assert g["ti2v_skipped"][:, 0].tolist() == [0, 1, 1, 0, 1, 0, 1, 0] and g["t2v_skipped"].sum().item() == 0
-    for mode, first in (("ti2v", z0), ("t2v", None)):
+    assert g["t2v_skip_skipped"][:, 0].tolist() == [0, 1, 1, 0, 1, 0, 0, 0]      # T2V mode WITH skipped steps (threshold 100)
+    for mode, first, thresh in (("ti2v", z0, 25.0), ("t2v", None, 25.0), ("t2v_skip", None, 100.0)):
         rec = []
         opipe.denoise_loop(sd, cfg, lat, ctx_p, ctx_n, 8, 5.0, 5.0, first, record=rec,
-                           tea_cache_l1_thresh=25.0, tea_cache_model_id="Wan2.1-I2V-14B-720P")
+                           tea_cache_l1_thresh=thresh, tea_cache_model_id="Wan2.1-I2V-14B-720P")
         for i, r in enumerate(rec):
             assert torch.equal(r, g[f"{mode}_step{i}"]), f"{mode} step {i}"
     with pytest.raises(ValueError):

@@ -1,11 +1,11 @@
 """The hand-scheduled DiT GEMMs against F.linear (hipBLASLt) on the DiT shapes: correctness + interleaved timing.
 
-    python tools/gemm_ab.py [--m 27280] [--only p] [--stamp-lib path]
+    python tools/gemm_ab.py [--m 27280] [--only p] [--only p|fp8] [--stamp-lib-p path]
 
-  w4: fg_gemm_bias_bf16, the data-parallel form (one 256x256 tile per workgroup)
-  p : fg_gemm_epilogue_bf16, the persistent form (one workgroup per CU, tile list, 256x256 or 256x192 tiles), mode 0, and its
-      residual modes (2: x + gate*y, 3: x + y) against the library GEMM followed by fg_gate_residual_bf16
---stamp-lib: a build of gen_gemm_w4.py --stamp: decode cycle stamps of the data-parallel form.
+  p  : fg_gemm_epilogue_bf16, the persistent form (one workgroup per CU, tile list, 256x256 tiles), mode 0, its residual modes
+       (2: x + gate*y, 3: x + y) against the library GEMM followed by fg_gate_residual_bf16, and mode 4 (GELU) against the library's
+       GELU epilogue (torch._addmm_activation)
+  fp8: fg_gemm_fp8_bf16 against torch._scaled_mm (row-wise scale_a) on the same e4m3 operands
 """
 import argparse
 import ctypes
@@ -43,7 +43,6 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--only", default="")
     ap.add_argument("--shapes", default="qkv,o,ffn.0,ffn.2")
-    ap.add_argument("--stamp-lib", default="")
     ap.add_argument("--stamp-lib-p", default="", help="a tools/build_gemm_variant.sh build with --stamp / -DFG_GEMM_STAMP")
     a = ap.parse_args()
     hip.load()
@@ -52,11 +51,6 @@ def main():
     rnd = lambda *s, sc=1.0: (torch.randn(s, generator=g, device=dev, dtype=torch.float32) * sc).to(torch.bfloat16)  # noqa: E731
     shapes = [("qkv", 3072, 9216), ("o", 3072, 3072), ("ffn.0", 3072, 14336), ("ffn.2", 14336, 3072)]
     shapes = [s for s in shapes if s[0] in a.shapes.split(",")]
-    stamp = None
-    if a.stamp_lib:
-        stamp = ctypes.CDLL(os.path.abspath(a.stamp_lib))
-        stamp.fg_gemm_bias_bf16.restype = ctypes.c_int
-        stamp.fg_gemm_bias_bf16.argtypes = hip._SIGNATURES["fg_gemm_bias_bf16"]
     stamp_p = None
     if a.stamp_lib_p:
         stamp_p = ctypes.CDLL(os.path.abspath(a.stamp_lib_p))
@@ -72,13 +66,6 @@ def main():
         ref32 = x[rows].float() @ w.float().t() + b.float()
         e_ref = (ref[rows].float() - ref32).abs().max().item()
         fns = {"hipBLASLt": lambda: F.linear(x, w, b)}
-        if a.only in ("", "w4") and n % 256 == 0:
-            out = hip.gemm_bias(x, w, b)
-            torch.cuda.synchronize()
-            e_out = (out[rows].float() - ref32).abs().max().item()
-            print(f"{name}: max|lib - f32| {e_ref:.4f}, max|w4 - f32| {e_out:.4f}, bit-identical to the library: "
-                  f"{(out == ref).float().mean().item():.6f}", flush=True)
-            fns["w4"] = lambda: hip.gemm_bias(x, w, b, out=out)
         if a.only in ("", "p"):
             outp = torch.full_like(ref, float("nan"))
             hip.gemm_epilogue(x, w, b, out=outp)
@@ -105,6 +92,28 @@ def main():
                 y_buf = torch.empty_like(ref)
                 fns["hipBLASLt + gate_residual"] = lambda: hip.gate_residual(resid, torch.addmm(b, x, w.t(), out=y_buf), mod, 2, out=resid)
                 fns["p mode 2"] = lambda: hip.gemm_epilogue(x, w, b, out=resid, residual=True, mod=mod, gate_idx=2)
+            if name == "ffn.0":      # GELU(tanh) in the store against the library's GELU epilogue
+                got = hip.gemm_epilogue(x, w, b, act="gelu_tanh")
+                want = torch._addmm_activation(b, x, w.t(), use_gelu=True)
+                torch.cuda.synchronize()
+                d = (got.float() - want.float()).abs()
+                print(f"   mode 4 (gelu): max |own - library epilogue| {d.max().item():.4f}, identical {(got == want).float().mean().item():.4f}", flush=True)
+                outg = torch.empty_like(ref)
+                fns["hipBLASLt + gelu epilogue"] = lambda: torch._addmm_activation(b, x, w.t(), use_gelu=True)
+                fns["p mode 4 (gelu)"] = lambda: hip.gemm_epilogue(x, w, b, out=outg, act="gelu_tanh")
+        if a.only in ("", "fp8"):
+            xq, sc = hip.fp8_quant_rows(x)
+            w8 = w.to(torch.float8_e4m3fn)
+            ones = torch.ones((1, n), device=dev)
+            lib8 = torch._scaled_mm(xq, w8.T, scale_a=sc, scale_b=ones, bias=b, out_dtype=torch.bfloat16)
+            own8 = hip.gemm_fp8(xq, sc, w8, b)
+            torch.cuda.synchronize()
+            d = (own8.float() - lib8.float()).abs()
+            print(f"{name} fp8: max |own - torch._scaled_mm| {d.max().item():.4f} (max |y| {lib8.float().abs().max().item():.2f}), identical "
+                  f"{(own8 == lib8).float().mean().item():.5f}", flush=True)
+            out8 = torch.empty_like(lib8)
+            fns["fp8 torch._scaled_mm"] = lambda: torch._scaled_mm(xq, w8.T, scale_a=sc, scale_b=ones, bias=b, out_dtype=torch.bfloat16)
+            fns["fp8 own"] = lambda: hip.gemm_fp8(xq, sc, w8, b, out=out8)
         times = timeit(fns, a.rounds)
         fl = 2.0 * a.m * k * n
         for kk, ts in times.items():
@@ -125,18 +134,6 @@ def main():
                   f"k-loop {np.median(w0[:, 0] / tiles):.0f} ({np.median(w0[:, 0] / tiles) / (k // 64):.0f} per 64-k step), epilogue "
                   f"{np.median(w0[:, 1] / tiles):.0f}, wait {np.median(w0[:, 2] / tiles):.0f} cycles; kernel {np.median(w0[:, 4]):.0f} cycles "
                   f"(max {w0[:, 4].max():.0f}), clock {clk:.0f} MHz; sum of parts {np.median((w0[:, 0] + w0[:, 1] + w0[:, 2])):.0f}", flush=True)
-        if stamp is not None:
-            o2 = torch.zeros_like(ref)
-            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for _ in range(3):
-                stamp.fg_gemm_bias_bf16(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), o2.data_ptr(), n, a.m, n, k, 0, st)
-            torch.cuda.synchronize()
-            raw = o2[0::256, :].contiguous().view(torch.int32).view(-1, n // 256, 128)[:, :, :4].reshape(-1, 4).cpu().double()
-            raw = raw[raw[:, 2] > 0]
-            per = (raw[:, 0] / raw[:, 2]).median().item()
-            clk = (raw[:, 0] / raw[:, 1] * 100).median().item()
-            tot = raw[:, 3].median().item()
-            print(f"   stamp: {len(raw)} tiles, {per:.0f} cycles per 64-MFMA step, clock {clk:.0f} MHz, loop {raw[:, 0].median().item():.0f} of {tot:.0f} cycles per tile", flush=True)
 
 
 if __name__ == "__main__":
