@@ -36,6 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 MFMA (block-scaled f8f6f4 form), same guide
 # HBM bytes per self-attention launch from rocprofv3 PMC passes of the SAME kernel and shape (profiles/r02_attn_w4_pmc.json:
 # separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB units, gfx950 x2 correction on FETCH_SIZE), keyed by (Nq, Nkv, H).
 # PMC collection cannot run inside the timed bench; other shapes report null.
@@ -82,7 +83,7 @@ class KernelTimer:
     blocks (wan_video_dit.gemm_bias*)."""
 
     def __init__(self):
-        self.attn, self.conv, self.gemm, self.gemm_own = [], [], [], []
+        self.attn, self.conv, self.gemm, self.gemm_own, self.gemm_fp8 = [], [], [], [], []
 
     @staticmethod
     def _events():
@@ -92,13 +93,13 @@ class KernelTimer:
         from fairygen_amd import hip, wan_video_dit
         self._orig = {"attention": hip.attention, "conv3d_cl": hip.conv3d_cl}
         self._orig_gemm = {n: getattr(wan_video_dit, n) for n in ("gemm_bias", "gemm_bias_gelu", "gemm_bias_tuned", "gemm_bias_own",
-                                                                   "gemm_residual")}
+                                                                   "gemm_bias_gelu_own", "gemm_residual", "gemm_fp8_own")}
         timer, lib = self, hip.load()
 
-        def timed_attention(q, k, v, num_heads, out=None):
+        def timed_attention(q, k, v, num_heads, out=None, scale=None):
             s, e = timer._events()
             s.record()
-            r = timer._orig["attention"](q, k, v, num_heads, out)
+            r = timer._orig["attention"](q, k, v, num_heads, out, scale)
             e.record()
             timer.attn.append((q.shape[1], k.shape[1], num_heads, s, e))
             return r
@@ -120,7 +121,15 @@ class KernelTimer:
                 s.record()
                 r = timer._orig_gemm[name](x, weight, bias)
                 e.record()
-                (timer.gemm_own if name == "gemm_bias_own" else timer.gemm).append((x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], s, e))
+                (timer.gemm_own if name.endswith("_own") else timer.gemm).append((x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], s, e))
+                return r
+
+            def fn_fp8(xq, scale_a, w8, bias):
+                s, e = timer._events()
+                s.record()
+                r = timer._orig_gemm[name](xq, scale_a, w8, bias)
+                e.record()
+                timer.gemm_fp8.append((xq.shape[0], w8.shape[1], w8.shape[0], s, e))
                 return r
 
             def fn_residual(x, a, weight, bias, mod=None, gate_idx=None):
@@ -130,7 +139,7 @@ class KernelTimer:
                 e.record()
                 timer.gemm_own.append((a.numel() // a.shape[-1], weight.shape[1], weight.shape[0], s, e))
                 return r
-            return fn_residual if name == "gemm_residual" else fn
+            return fn_residual if name == "gemm_residual" else fn_fp8 if name == "gemm_fp8_own" else fn
         hip.attention, hip.conv3d_cl = timed_attention, timed_conv
         for n in self._orig_gemm:
             setattr(wan_video_dit, n, timed_gemm(n))
@@ -181,10 +190,16 @@ class KernelTimer:
         rec = [(2.0 * m * k * n, s.elapsed_time(e) * 1e-3) for m, k, n, s, e in self.gemm_own]
         if rec:
             t, fl = sum(r[1] for r in rec), sum(r[0] for r in rec)
-            out.append({"kernel": "gemm_p_kernel (fg_gemm_epilogue_bf16: persistent hand-scheduled DiT GEMM; o / cross-o / ffn.2 with the "
-                                  "gate*y + x residual in the store, cross q)",
+            out.append({"kernel": "gemm_p_kernel<bf16> (fg_gemm_epilogue_bf16: persistent hand-scheduled DiT GEMM; qkv, cross q, ffn.0 with GELU in "
+                                  "the store, o / cross-o / ffn.2 with the gate*y + x residual in the store)",
                         "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4), "launches": len(rec), "total_s": round(t, 3)})
+        rec = [(2.0 * m * k * n, s.elapsed_time(e) * 1e-3) for m, k, n, s, e in self.gemm_fp8 if m >= 1024]
+        if rec:
+            t, fl = sum(r[1] for r in rec), sum(r[0] for r in rec)
+            out.append({"kernel": "gemm_p_kernel<e4m3> (fg_gemm_fp8_bf16: the fp8 Linear mode's row-scaled matmul, v_mfma_f32_32x32x64_f8f6f4)",
+                        "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / t / 1e12 / PEAK_FP8_TFLOPS, 4), "launches": len(rec), "total_s": round(t, 3)})
         return out
 
 
@@ -424,9 +439,15 @@ def main():
                        "weights": "random-init bf16, reference key/shape set"},
             "roofline": roofline,
         }
-        line["config"]["gelu"] = "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel"
         from fairygen_amd import wan_video as _wv, wan_video_dit as _wd
-        line["config"]["dit_gemm_backend"] = _wd.GEMM_BACKEND + " (FAIRYGEN_GEMM: which Linears run on gemm_p_kernel instead of hipBLASLt)"
+        line["config"]["gelu"] = ("gemm_p_kernel epilogue (mode 4)" if _wd.GEMM_BACKEND == "all" and args.linear_dtype == "bf16" else
+                                  "fused into ffn.2's row quantisation" if args.linear_dtype == "fp8" else
+                                  "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel")
+        line["config"]["dit_gemm_backend"] = _wd.GEMM_BACKEND + " (FAIRYGEN_GEMM: which Linears run on gemm_p_kernel instead of hipBLASLt; 'all' = every Linear of the blocks)"
+        if args.linear_dtype == "fp8":
+            line["config"]["fp8_gemm"] = _wd.FP8_GEMM + " (FAIRYGEN_FP8_GEMM: own = fg_gemm_fp8_bf16, lib = torch._scaled_mm)"
+        line["config"]["attention_scale"] = ("2^-3 / log2(e) with 1.0201 folded into q's RoPE table: exact pre-multiplied form of attn_fwd_w4_kernel"
+                                             if pipe.dit.attn_scale()[0] is not None else "1/sqrt(d): plain form of attn_fwd_w4_kernel")
         line["config"]["cfg_shared_prefix"] = ("block 0's self-attention computed once per step for both CFG forwards (identical inputs, bit-identical "
                                                "result; FAIRYGEN_CFG_SHARE=0 computes it twice)") if _wv.CFG_SHARE_PREFIX else "off"
         line["config"]["cross_attention_kv"] = ("computed at the first step, kept for the loop (prompt and weights are constant; bit-identical; "

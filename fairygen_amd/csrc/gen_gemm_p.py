@@ -30,9 +30,18 @@ from gen_attn_w4 import Emitter, Item, schedule, vr, ar, sr
 STAGE, XOFF = 65536, 32768
 TAB = 131072                           # tile records (48 B each) above the two stages
 SB = 36                                # s32..s34 are reserved by the compiler (stack / frame / base pointer)
-S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, GD=16, WAVE=20, NK=21, LDA=22, LDC=23, KOFF=24, T=25, TI=26, TMP0=27,
-                                TMP1=28, TMP2=29, WDST=30, XDST=31, KW=32, FLAGS=33, FIRST=34, GLD=35, TMP64=36, ST1=38,
-                                GBASE=40, M0ROW=42, KIND=43, REC=44).items()}      # REC: 16 SGPRs of the current tile record
+S = {k: v + SB for k, v in dict(XD=0, WD=4, CD=8, BD=12, GD=16, WAVE=20, NK=21, XHOME=22, LDC=23, KOFF=24, T=25, UNIT=26, TMP0=27,
+                                TMP1=28, TMP2=29, WDST=30, XDST=31, NTILES=32, FLAGS=33, FIRST=34, GLD=35, TMP64=36, ST1=38,
+                                KARG=40, M0ROW=42, KIND=43, REC=44).items()}      # REC: 16 SGPRs of the current tile record
+# The scheduling / shape block at the start of the kernel arguments (struct GemmSched in dit_gemm.hip, same offsets): the body reads it
+# with scalar loads through KARG
+K_A, K_W, K_C, K_BIAS, K_WS, K_CURS, K_GATE, K_SCALE = 0, 8, 16, 24, 32, 40, 48, 56
+K_DIMS0 = 64       # M, lda bytes, ldc bytes, k bytes
+K_DIMS1 = 80       # nk, tiles_m, tiles_n, gm | gm * tiles_n, its division magic, nxcd, grid
+K_QD = 112         # qd, rm, per, flags
+K_EPI = 128        # first_rows, gate ld bytes, gate bytes, M - 1
+K_PLAN = 144       # two plans of 8 dwords (XCDs with qd + 1 / qd tiles): n_whole, n_main, n_tail, split, split magic, base, extra, full * per
+PIECE_BYTES = 256 * 256 * 4
 NSREG = 62                             # ... and the L2-prefetch lane shifts (s96, s97)
 PF_SX, PF_SW = SB + 60, SB + 61
 F0, F1 = 0, 32
@@ -105,17 +114,31 @@ def acc(ni, mi, j=0):
 
 
 def emit_setup(E, C, first=True):
-    """%0 kernarg-independent scalars: %0 wave, %1 K/64, %2 lda bytes, %3 ldc bytes, %4 K bytes, %5 flags, %6 first_rows (gate class)."""
-    for n, name in enumerate(["WAVE", None, "LDA", "LDC", "KW", "FLAGS", "FIRST"]):      # %1 (K/64) is in every tile record now
-        if name:
-            E.e(f"s_mov_b32 {sr(S[name])}, %{n}")
+    """Asm operands: %0 wave, %1 kernel argument segment (64-bit; struct GemmSched at its start), %2 the workgroup's home XCD (blockIdx %
+    nxcd).  Everything else comes from the argument segment.  LDA / KW: operand row strides in bytes (REC is scratch here)."""
+    if first:
+        E.e(f"s_mov_b32 {sr(S['WAVE'])}, %0")
+        E.e(f"s_mov_b64 {sr(S['KARG'], 2)}, %1")
+        E.e(f"s_mov_b32 {sr(S['XHOME'])}, %2")
+        E.e(f"s_mov_b32 {sr(S['NTILES'])}, 0")
+    E.e(f"s_load_dwordx4 {sr(S['REC'], 4)}, {sr(S['KARG'], 2)}, {K_DIMS0}")
+    E.e(f"s_load_dwordx4 {sr(S['REC'] + 4, 4)}, {sr(S['KARG'], 2)}, {K_QD}")
+    E.e(f"s_load_dwordx4 {sr(S['REC'] + 8, 4)}, {sr(S['KARG'], 2)}, {K_EPI}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    LDA, KW = S["REC"] + 1, S["REC"] + 3
+    E.e(f"s_mov_b32 {sr(S['LDC'])}, {sr(S['REC'] + 2)}")
+    E.e(f"s_mov_b32 {sr(S['FLAGS'])}, {sr(S['REC'] + 7)}")
+    E.e(f"s_mov_b32 {sr(S['FIRST'])}, {sr(S['REC'] + 8)}")
+    E.e(f"s_mov_b32 {sr(S['GLD'])}, {sr(S['REC'] + 9)}")
+    E.e(f"s_mov_b32 {sr(S['GD'] + 2)}, {sr(S['REC'] + 10)}")
+    if FP8:
+        E.e(f"s_mov_b32 {sr(S_MLAST)}, {sr(S['REC'] + 11)}")
+        E.e(f"s_load_dwordx2 {sr(S_SCB, 2)}, {sr(S['KARG'], 2)}, {K_SCALE}")
     for base in (S["XD"], S["WD"], S["CD"], S["BD"], S["GD"]):
         E.e(f"s_mov_b32 {sr(base + 3)}, 0x00020000")
     E.e(f"s_mul_i32 {sr(S['WDST'])}, {sr(S['WAVE'])}, {C.npw * 1024}")
     E.e(f"s_lshl_b32 {sr(S['XDST'])}, {sr(S['WAVE'])}, 13")
     E.e(f"s_add_u32 {sr(S['XDST'])}, {sr(S['XDST'])}, {C.xoff}")
-    if first:
-        E.e(f"s_mov_b32 {sr(S['TI'])}, 0")
     E.e(f"v_mov_b32 {vr(255)}, 0")
     E.nops(4)
     L, R, HH, SW, T0, T1, T2 = (V_T + i for i in range(7))
@@ -147,7 +170,7 @@ def emit_setup(E, C, first=True):
     E.e(f"v_lshrrev_b32 {vr(T0)}, 3, {vr(L)}")
     E.e(f"v_lshrrev_b32 {vr(T1)}, 4, {vr(L)}")
     E.e(f"v_and_b32 {vr(T2)}, 7, {vr(L)}")
-    for op, npw, base, stride in (("W", C.npw, V_DW, S["KW"]), ("X", 8, V_DX, S["LDA"])):
+    for op, npw, base, stride in (("W", C.npw, V_DW, KW), ("X", 8, V_DX, LDA)):
         E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, {8 * npw}")
         for i in range(npw):
             E.e(f"v_add_u32 {vr(SW)}, {4 * (i & 1)}, {vr(T1)}")
@@ -161,7 +184,7 @@ def emit_setup(E, C, first=True):
     # L2 prefetch offsets: lane l <-> row l of this wave's 8*npw weight rows / 64 activation rows
     E.e(f"s_mul_i32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, {8 * C.npw}")
     E.e(f"v_add_u32 {vr(V_PW)}, {sr(S['TMP0'])}, {vr(L)}")
-    E.e(f"v_mul_lo_u32 {vr(V_PW)}, {vr(V_PW)}, {sr(S['KW'])}")
+    E.e(f"v_mul_lo_u32 {vr(V_PW)}, {vr(V_PW)}, {sr(KW)}")
     if 8 * C.npw < 64:
         E.e(f"v_cmp_le_u32 vcc, {8 * C.npw}, {vr(L)}")
         E.e(f"v_mov_b32 {vr(T2)}, {OOB}")
@@ -169,7 +192,7 @@ def emit_setup(E, C, first=True):
         E.e(f"v_cndmask_b32 {vr(V_PW)}, {vr(V_PW)}, {vr(T2)}, vcc")
     E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 6")
     E.e(f"v_add_u32 {vr(V_PX)}, {sr(S['TMP0'])}, {vr(L)}")
-    E.e(f"v_mul_lo_u32 {vr(V_PX)}, {vr(V_PX)}, {sr(S['LDA'])}")
+    E.e(f"v_mul_lo_u32 {vr(V_PX)}, {vr(V_PX)}, {sr(LDA)}")
     # epilogue lane constants (see the register map)
     I4, I15 = T0, T1
     E.e(f"v_and_b32 {vr(R)}, 31, {vr(L)}")
@@ -202,6 +225,7 @@ def emit_setup(E, C, first=True):
     E.e(f"v_add_u32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(V_GOFF)}")
     if C.nb < 4:
         E.e(f"v_cndmask_b32 {vr(V_SOFF)}, {vr(V_SOFF)}, {vr(T2)}, vcc")
+    E.e("s_waitcnt lgkmcnt(0)")
     E.nops(2)
 
 
@@ -217,40 +241,226 @@ def emit_stamp(E, acc):
     E.e(f"s_mov_b32 {sr(S['ST1'])}, {sr(S['TMP64'])}")
 
 
-def emit_load_record(E, part):
-    """Tile record TI (48 B in LDS): part 'A' = x base, w base, x bytes -> XD, WD (and REC for part B); sets SCC = 0 / jumps at the end."""
-    T0 = V_REC
-    if part == "A":
-        E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['TI'])}, 6")
-        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {TAB}")
-        E.e(f"v_mov_b32 {vr(T0)}, {sr(S['TMP0'])}")
-        E.e(f"ds_read_b128 {vr(T0 + 2, 4)}, {vr(T0)}")
-        E.e(f"ds_read_b128 {vr(T0 + 6, 4)}, {vr(T0)} offset:16")
-        E.e(f"ds_read_b128 {vr(T0 + 10, 4)}, {vr(T0)} offset:32")
-        E.e(f"ds_read_b128 {vr(T0 + 14, 4)}, {vr(T0)} offset:48")
-        E.e("s_waitcnt lgkmcnt(0)")
-        for i in range(16):
-            E.e(f"v_readfirstlane_b32 {sr(S['REC'] + i)}, {vr(T0 + 2 + i)}")
-        E.nops(2)
-        # record: x_base(0,1) w_base(2,3) c_base(4,5) bias_base(6,7) x_bytes(8) c_bytes(9) valid(10) m0(11) n0_bytes(12) w_bytes(13)
-        E.e(f"s_mov_b64 {sr(S['XD'], 2)}, {sr(S['REC'], 2)}")
-        E.e(f"s_mov_b32 {sr(S['XD'] + 2)}, {sr(S['REC'] + 8)}")
-        E.e(f"s_mov_b64 {sr(S['WD'], 2)}, {sr(S['REC'] + 2, 2)}")
-        E.e(f"s_mov_b32 {sr(S['WD'] + 2)}, {sr(S['REC'] + 13)}")
-        # cooperative L2 prefetch: this CU pulls activation rows l % 8 == record[14] and weight rows l % 4 == record[15]
-        E.e(f"s_and_b32 {sr(PF_SX)}, {sr(S['REC'] + 14)}, 0xff")
-        E.e(f"s_lshr_b32 {sr(PF_SW)}, {sr(S['REC'] + 14)}, 8")
-        # the tile's k range: record[15] = first byte of the range in a row | k-steps << 16 (a whole tile: 0 | K/64 << 16; a piece
-        # of a k-split tile of the last round: its part, the fp32 accumulators then go to the workspace: KIND 2)
-        E.e(f"s_lshr_b32 {sr(S['NK'])}, {sr(S['REC'] + 15)}, 16")
+V_GRAB = lambda: V_TB + 9       # noqa: E731  wave 0, lane 0: the unit index the cursor returned (in flight during the k-loop)
+V_SLOT = lambda: V_TB + 8       # noqa: E731  LDS address of this lane's broadcast word (TAB + 256 * wave + 4 * lane; readers take wave 0's lane 0)
+
+
+def emit_grab_issue(E, tail):
+    """Wave 0, lane 0: unit index <- atomic add on the home XCD's cursor of this list (device scope), into V_GRAB; every wave: V_SLOT.
+    No wait here: the k-loop's counted vmcnt waits retire it (it is older than every load of the loop)."""
+    skip = E.label("grabskip")
+    # V_SLOT: every lane its own LDS word (TAB + 256 * wave + 4 * lane): the cursor's answer exists in wave 0's lane 0 only, and 64 lanes
+    # storing different values to ONE address would leave some other lane's there
+    E.e(f"v_mbcnt_lo_u32_b32 {vr(V_SLOT())}, -1, 0")
+    E.e(f"v_mbcnt_hi_u32_b32 {vr(V_SLOT())}, -1, {vr(V_SLOT())}")
+    E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['WAVE'])}, 8")
+    E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, {TAB}")
+    E.e(f"v_lshl_add_u32 {vr(V_SLOT())}, {vr(V_SLOT())}, 2, {sr(S['TMP0'])}")
+    E.e(f"s_cmp_lg_u32 {sr(S['WAVE'])}, 0")
+    E.e(f"s_cbranch_scc1 {skip}")
+    E.e(f"s_load_dwordx2 {sr(S['TMP64'], 2)}, {sr(S['KARG'], 2)}, {K_CURS}")
+    E.e(f"s_lshl_b32 {sr(S['TMP0'])}, {sr(S['XHOME'])}, 2")
+    if tail:
+        E.e(f"s_add_u32 {sr(S['TMP0'])}, {sr(S['TMP0'])}, 32")
+    E.e(f"v_mov_b32 {vr(V_TB + 7)}, {sr(S['TMP0'])}")
+    E.e(f"v_mov_b32 {vr(V_GRAB())}, 1")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e("s_mov_b64 exec, 1")
+    E.e(f"global_atomic_add {vr(V_GRAB())}, {vr(V_TB + 7)}, {vr(V_GRAB())}, {sr(S['TMP64'], 2)} sc0 sc1")
+    E.e("s_mov_b64 exec, -1")
+    E.e(f"{skip}:")
+
+
+def emit_grab_read(E):
+    """UNIT <- wave 0's broadcast word (written to LDS before the barrier the caller has passed)."""
+    E.e(f"v_mov_b32 {vr(V_TB + 7)}, {TAB}")
+    E.e(f"ds_read_b32 {vr(V_TB + 6)}, {vr(V_TB + 7)}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e(f"v_readfirstlane_b32 {sr(S['UNIT'])}, {vr(V_TB + 6)}")
+    E.nops(2)
+
+
+def emit_grab_sync(E, tail):
+    """The first unit of a body: grab, publish, read.  The leading barrier keeps wave 0's write behind every earlier read of the word."""
+    E.e("s_barrier")
+    emit_grab_issue(E, tail)
+    E.e("s_waitcnt vmcnt(0)")
+    E.e(f"ds_write_b32 {vr(V_SLOT())}, {vr(V_GRAB())}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e("s_barrier")
+    emit_grab_read(E)
+
+
+def emit_make_record(E, tail):
+    """Unit UNIT of the home XCD's list -> the 16-dword tile record in REC (REC+10 = 0: the list is exhausted), XD / WD / NK and the
+    prefetch lanes.  What round 2's wrapper wrote into an LDS table per workgroup, now computed per unit from the static plan in the
+    kernel arguments: which UNITS exist and what they compute is fixed by the shape (TailPlan in dit_gemm.hip); which workgroup takes
+    which unit is decided by the cursor.  main list: whole tiles in raster order, then the k-range pieces of the left-over tiles;
+    tail list: their 64-column pieces."""
+    R = S["REC"]
+    T0, T1, T2, T3, T4, T5, T6 = S["TMP0"], S["TMP1"], S["TMP2"], S["TMP64"], S["TMP64"] + 1, S["T"], S["KOFF"]
+    P = S["XD"]                      # the plan (8 dwords) sits in XD / WD until they are set at the end
+    none, have = E.label("recnone"), E.label("rechave")
+    whole, gotlog = E.label("recwhole"), E.label("reclog")
+    e = E.e
+    e(f"s_load_dwordx8 {sr(R, 8)}, {sr(S['KARG'], 2)}, {K_DIMS1}")          # R0 nk, R1 tiles_m, R2 tiles_n, R3 gm, R4 gm*tiles_n, R5 magic, R6 nxcd, R7 grid
+    e(f"s_load_dwordx4 {sr(R + 8, 4)}, {sr(S['KARG'], 2)}, {K_QD}")          # R8 qd, R9 rm, R10 per
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_mov_b32 {sr(T0)}, {K_PLAN + 32}")
+    e(f"s_cmp_lt_u32 {sr(S['XHOME'])}, {sr(R + 9)}")
+    e(f"s_cselect_b32 {sr(T0)}, {K_PLAN}, {sr(T0)}")
+    e(f"s_load_dwordx8 {sr(P, 8)}, {sr(S['KARG'], 2)}, {sr(T0)}")             # P0 n_whole, P1 n_main, P2 n_tail, P3 split, P4 split magic, P5 base, P6 extra, P7 full*per
+    e(f"s_min_u32 {sr(T1)}, {sr(S['XHOME'])}, {sr(R + 9)}")
+    e(f"s_mul_i32 {sr(T2)}, {sr(S['XHOME'])}, {sr(R + 8)}")
+    e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(T1)}")                              # T2 = start: first logical tile of this XCD
+    e("s_waitcnt lgkmcnt(0)")
+    # in the list?  (and no workgroup takes more than 65535 units whatever the cursor says: an exit condition every wave reaches)
+    e(f"s_cmp_lt_u32 {sr(S['UNIT'])}, {sr(P + (2 if tail else 1))}")
+    e(f"s_cselect_b32 {sr(T1)}, 1, 0")
+    e(f"s_cmp_lt_u32 {sr(S['NTILES'])}, 0xffff")
+    e(f"s_cselect_b32 {sr(T1)}, {sr(T1)}, 0")
+    e(f"s_cmp_eq_u32 {sr(T1)}, 1")
+    e(f"s_cbranch_scc1 {have}")
+    e(f"s_mov_b32 {sr(R + 10)}, 0")
+    e(f"s_branch {none}")
+    e(f"{have}:")
+    # ---- unit -> logical tile T2, kind R10 (1 whole / column piece, 2 k-range piece), k range (T5 = k0, R0 = k-steps), T6 = piece / slot
+    e(f"s_mov_b32 {sr(R + 10)}, 1")
+    e(f"s_mov_b32 {sr(T5)}, 0")
+    if tail:
+        e(f"s_lshr_b32 {sr(T1)}, {sr(S['UNIT'])}, 2")
+        e(f"s_and_b32 {sr(T6)}, {sr(S['UNIT'])}, 3")                            # T6 = column piece
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(P + 7)}")
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(T1)}")
     else:
-        E.e(f"s_mov_b64 {sr(S['CD'], 2)}, {sr(S['REC'] + 4, 2)}")
-        E.e(f"s_mov_b32 {sr(S['CD'] + 2)}, {sr(S['REC'] + 9)}")
-        E.e(f"s_mov_b64 {sr(S['BD'], 2)}, {sr(S['REC'] + 6, 2)}")
-        E.e(f"s_mov_b32 {sr(S['M0ROW'])}, {sr(S['REC'] + 11)}")            # m0 of the tile (token class of a row: m0 + row < FIRST)
-        E.e(f"s_mov_b32 {sr(S['KIND'])}, {sr(S['REC'] + 10)}")
-        E.e(f"s_add_u32 {sr(S['GD'])}, {sr(S['GBASE'])}, {sr(S['REC'] + 12)}")     # gate vector at the tile's first column
-        E.e(f"s_addc_u32 {sr(S['GD'] + 1)}, {sr(S['GBASE'] + 1)}, 0")
+        e(f"s_cmp_lt_u32 {sr(S['UNIT'])}, {sr(P)}")
+        e(f"s_cbranch_scc1 {whole}")
+        e(f"s_sub_u32 {sr(T6)}, {sr(S['UNIT'])}, {sr(P)}")                      # p: index among the k-range pieces
+        e(f"s_mul_hi_u32 {sr(T1)}, {sr(T6)}, {sr(P + 4)}")                      # left-over tile index = p / split
+        e(f"s_mul_i32 {sr(T0)}, {sr(T1)}, {sr(P + 3)}")
+        e(f"s_sub_u32 {sr(T0)}, {sr(T6)}, {sr(T0)}")                            # j = p % split
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(P + 7)}")
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(T1)}")
+        e(f"s_mov_b32 {sr(R + 10)}, 2")
+        e(f"s_min_u32 {sr(T1)}, {sr(T0)}, {sr(P + 6)}")
+        e(f"s_mul_i32 {sr(T5)}, {sr(T0)}, {sr(P + 5)}")
+        e(f"s_add_u32 {sr(T5)}, {sr(T5)}, {sr(T1)}")                            # k0 = j * base + min(j, extra)
+        e(f"s_cmp_lt_u32 {sr(T0)}, {sr(P + 6)}")
+        e(f"s_cselect_b32 {sr(T1)}, 1, 0")
+        e(f"s_add_u32 {sr(R)}, {sr(P + 5)}, {sr(T1)}")                          # k-steps = base + (j < extra)
+        e(f"s_branch {gotlog}")
+        e(f"{whole}:")
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(S['UNIT'])}")
+        e(f"{gotlog}:")
+    # ---- logical tile -> (mt, nt): grouped raster, gm row tiles at a time, m fastest inside a group
+    e(f"s_mul_hi_u32 {sr(T1)}, {sr(T2)}, {sr(R + 5)}")                          # group
+    e(f"s_mul_i32 {sr(T0)}, {sr(T1)}, {sr(R + 4)}")
+    e(f"s_sub_u32 {sr(T2)}, {sr(T2)}, {sr(T0)}")                                # in_group
+    e(f"s_mul_i32 {sr(T1)}, {sr(T1)}, {sr(R + 3)}")                             # group * gm = first row tile of the group
+    e(f"s_sub_u32 {sr(T0)}, {sr(R + 1)}, {sr(T1)}")
+    e(f"s_min_u32 {sr(T0)}, {sr(T0)}, {sr(R + 3)}")                             # row tiles in this group (1..4)
+    e(f"s_mov_b32 {sr(T3)}, 0x40000000")
+    e(f"s_cmp_eq_u32 {sr(T0)}, 2")
+    e(f"s_cselect_b32 {sr(T3)}, 0x80000000, {sr(T3)}")
+    e(f"s_cmp_eq_u32 {sr(T0)}, 3")
+    e(f"s_cselect_b32 {sr(T3)}, 0x55555556, {sr(T3)}")
+    e(f"s_mul_hi_u32 {sr(T3)}, {sr(T2)}, {sr(T3)}")
+    e(f"s_cmp_eq_u32 {sr(T0)}, 1")
+    e(f"s_cselect_b32 {sr(T3)}, {sr(T2)}, {sr(T3)}")                            # nt = in_group / rows
+    e(f"s_mul_i32 {sr(T4)}, {sr(T3)}, {sr(T0)}")
+    e(f"s_sub_u32 {sr(T2)}, {sr(T2)}, {sr(T4)}")
+    e(f"s_add_u32 {sr(T1)}, {sr(T1)}, {sr(T2)}")                                # mt
+    # prefetch lanes (REC+14), k range (REC+15), m0 (REC+11), n0 bytes (REC+12)
+    e(f"s_and_b32 {sr(T0)}, {sr(T1)}, 3")
+    e(f"s_lshl_b32 {sr(T0)}, {sr(T0)}, 8")
+    if tail:
+        e(f"s_or_b32 {sr(R + 14)}, {sr(T0)}, {sr(T6)}")
+    else:
+        e(f"s_and_b32 {sr(T2)}, {sr(T3)}, 7")
+        e(f"s_or_b32 {sr(R + 14)}, {sr(T0)}, {sr(T2)}")
+    e(f"s_lshl_b32 {sr(T0)}, {sr(R)}, 16")
+    e(f"s_lshl_b32 {sr(T5)}, {sr(T5)}, 7")
+    e(f"s_or_b32 {sr(R + 15)}, {sr(T0)}, {sr(T5)}")
+    e(f"s_lshl_b32 {sr(R + 11)}, {sr(T1)}, 8")                                 # m0
+    e(f"s_lshl_b32 {sr(T3)}, {sr(T3)}, 8")                                     # n0
+    if tail:
+        e(f"s_lshl_b32 {sr(T0)}, {sr(T6)}, 6")
+        e(f"s_add_u32 {sr(T3)}, {sr(T3)}, {sr(T0)}")
+    e(f"s_lshl_b32 {sr(R + 12)}, {sr(T3)}, 1")
+    # ---- addresses.  T6 (k-range piece: p) -> workspace slot XHOME * per + p
+    e(f"s_load_dwordx4 {sr(R, 4)}, {sr(S['KARG'], 2)}, {K_DIMS0}")              # R0 M, R1 lda bytes, R2 ldc bytes, R3 k bytes
+    e(f"s_load_dwordx8 {sr(P, 8)}, {sr(S['KARG'], 2)}, {K_A}")                  # P0:1 a, P2:3 w, P4:5 c, P6:7 bias
+    e(f"s_load_dwordx2 {sr(R + 4, 2)}, {sr(S['KARG'], 2)}, {K_WS}")
+    e("s_waitcnt lgkmcnt(0)")
+    TN = 64 if tail else 256
+    e(f"s_sub_u32 {sr(T0)}, {sr(R)}, {sr(R + 11)}")
+    e(f"s_min_u32 {sr(T0)}, {sr(T0)}, 256")
+    e(f"s_sub_u32 {sr(T0)}, {sr(T0)}, 1")                                       # rows - 1
+    e(f"s_mul_i32 {sr(R + 8)}, {sr(T0)}, {sr(R + 1)}")
+    e(f"s_add_u32 {sr(R + 8)}, {sr(R + 8)}, {sr(R + 3)}")                       # x bytes
+    e(f"s_mul_i32 {sr(R + 9)}, {sr(T0)}, {sr(R + 2)}")
+    e(f"s_add_u32 {sr(R + 9)}, {sr(R + 9)}, {TN * 2}")                          # c bytes
+    e(f"s_mul_i32 {sr(R + 13)}, {sr(R + 3)}, {TN}")                             # w bytes
+    # bias + n0 bytes -> R6:7 (bias pointer P6:7)
+    e(f"s_add_u32 {sr(R + 6)}, {sr(P + 6)}, {sr(R + 12)}")
+    e(f"s_addc_u32 {sr(R + 7)}, {sr(P + 7)}, 0")
+    # c + m0 * ldc bytes + n0 bytes -> T0:T1 (64-bit), or the piece's workspace slot
+    e(f"s_mul_i32 {sr(T0)}, {sr(R + 11)}, {sr(R + 2)}")
+    e(f"s_mul_hi_u32 {sr(T1)}, {sr(R + 11)}, {sr(R + 2)}")
+    e(f"s_add_u32 {sr(T0)}, {sr(T0)}, {sr(R + 12)}")
+    e(f"s_addc_u32 {sr(T1)}, {sr(T1)}, 0")
+    e(f"s_add_u32 {sr(T0)}, {sr(T0)}, {sr(P + 4)}")
+    e(f"s_addc_u32 {sr(T1)}, {sr(T1)}, {sr(P + 5)}")
+    if not tail:
+        notpiece = E.label("recnotpiece")
+        e(f"s_cmp_lg_u32 {sr(R + 10)}, 2")
+        e(f"s_cbranch_scc1 {notpiece}")
+        e(f"s_load_dword {sr(T2)}, {sr(S['KARG'], 2)}, {K_QD + 8}")             # per
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_mul_i32 {sr(T2)}, {sr(T2)}, {sr(S['XHOME'])}")
+        e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(T6)}")                            # slot
+        e(f"s_lshr_b32 {sr(T1)}, {sr(T2)}, 14")
+        e(f"s_lshl_b32 {sr(T0)}, {sr(T2)}, 18")                                 # slot * PIECE_BYTES (2^18)
+        e(f"s_add_u32 {sr(T0)}, {sr(T0)}, {sr(R + 4)}")
+        e(f"s_addc_u32 {sr(T1)}, {sr(T1)}, {sr(R + 5)}")
+        e(f"s_mov_b32 {sr(R + 9)}, {PIECE_BYTES}")
+        e(f"{notpiece}:")
+    e(f"s_mov_b32 {sr(R + 4)}, {sr(T0)}")
+    e(f"s_mov_b32 {sr(R + 5)}, {sr(T1)}")
+    # a + m0 * lda bytes -> XD ; w + n0 * k bytes -> WD   (P0:3 are XD0:3: read the pointers before they are overwritten)
+    e(f"s_mul_i32 {sr(T0)}, {sr(R + 11)}, {sr(R + 1)}")
+    e(f"s_mul_hi_u32 {sr(T1)}, {sr(R + 11)}, {sr(R + 1)}")
+    e(f"s_mul_i32 {sr(T2)}, {sr(T3)}, {sr(R + 3)}")
+    e(f"s_mul_hi_u32 {sr(T4)}, {sr(T3)}, {sr(R + 3)}")
+    e(f"s_add_u32 {sr(T2)}, {sr(T2)}, {sr(P + 2)}")
+    e(f"s_addc_u32 {sr(T4)}, {sr(T4)}, {sr(P + 3)}")
+    e(f"s_add_u32 {sr(S['XD'])}, {sr(T0)}, {sr(P)}")
+    e(f"s_addc_u32 {sr(S['XD'] + 1)}, {sr(T1)}, {sr(P + 1)}")
+    e(f"s_mov_b32 {sr(S['XD'] + 2)}, {sr(R + 8)}")
+    e(f"s_mov_b32 {sr(S['XD'] + 3)}, 0x00020000")
+    e(f"s_mov_b32 {sr(S['WD'])}, {sr(T2)}")
+    e(f"s_mov_b32 {sr(S['WD'] + 1)}, {sr(T4)}")
+    e(f"s_mov_b32 {sr(S['WD'] + 2)}, {sr(R + 13)}")
+    e(f"s_mov_b32 {sr(S['WD'] + 3)}, 0x00020000")
+    # cooperative L2 prefetch lanes and the k range
+    e(f"s_and_b32 {sr(PF_SX)}, {sr(R + 14)}, 0xff")
+    e(f"s_lshr_b32 {sr(PF_SW)}, {sr(R + 14)}, 8")
+    e(f"s_lshr_b32 {sr(S['NK'])}, {sr(R + 15)}, 16")
+    e(f"s_add_u32 {sr(S['NTILES'])}, {sr(S['NTILES'])}, 1")
+    e(f"{none}:")
+
+
+def emit_load_record_b(E):
+    """The record's output side -> the descriptors the epilogue of this tile uses (kept until that epilogue is through)."""
+    E.e(f"s_mov_b64 {sr(S['CD'], 2)}, {sr(S['REC'] + 4, 2)}")
+    E.e(f"s_mov_b32 {sr(S['CD'] + 2)}, {sr(S['REC'] + 9)}")
+    E.e(f"s_mov_b64 {sr(S['BD'], 2)}, {sr(S['REC'] + 6, 2)}")
+    E.e(f"s_mov_b32 {sr(S['M0ROW'])}, {sr(S['REC'] + 11)}")            # m0 of the tile (token class of a row: m0 + row < FIRST)
+    E.e(f"s_mov_b32 {sr(S['KIND'])}, {sr(S['REC'] + 10)}")
+    E.e(f"s_load_dwordx2 {sr(S['GD'], 2)}, {sr(S['KARG'], 2)}, {K_GATE}")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e(f"s_add_u32 {sr(S['GD'])}, {sr(S['GD'])}, {sr(S['REC'] + 12)}")     # gate vector at the tile's first column
+    E.e(f"s_addc_u32 {sr(S['GD'] + 1)}, {sr(S['GD'] + 1)}, 0")
 
 
 def dma_piece(C, op, i, stage):
@@ -347,6 +557,9 @@ def build_iteration(E, C, stage, first, budget):
             add(Item(f"pf{op}", prefetch_lines(C, op, C.pf_dist), 8, earliest=min(last + 1 + 2 * n, C.gaps - 2),
                      deadline=min(last + (5 if FP8 else 9) + 2 * n, C.gaps - 1)))
             n_pf += 1
+    # wave w stores V_GRAB to its LDS word every step (wave 0's is the next unit's index once the cursor's answer has landed — from the
+    # second step on; the readers take it after the last step's barrier)
+    add(Item("grabpub", [f"ds_write_b32 {vr(V_SLOT())}, {vr(V_GRAB())}"], 2, earliest=max(C.gaps - 8, 0), deadline=C.gaps - 2, lds=1))
     gaps, load = schedule(items, C.gaps, budget)
     lds_issued, lds_done, done_at = 0, 0, {}
     for g in range(C.gaps):
@@ -632,20 +845,13 @@ def emit_epilogue(E, C, n_dma):
     E.e(f"{done}:")
 
 
-def emit_program(E, C, stamp, budget, first):
-    """One body: walks tile records from TI on until a record with valid = 0, and leaves TI on the record after it.  first: the
-    body that starts the kernel (TI = 0, stamp counters cleared); a later body re-derives every lane constant for its own tile
-    width and goes on reading the table where the previous one stopped."""
+def emit_program(E, C, stamp, budget, first, tail):
+    """One body: takes units of its list (main: whole tiles + k-range pieces; tail: 64-column pieces) from the home XCD's cursor until
+    the list is exhausted.  first: the body that starts the kernel; a later body re-derives every lane constant for its own tile width."""
     emit_setup(E, C, first)
-    # %7 gate base (64-bit: row 0 of the gate vector, column 0), %8 gate row stride in bytes (0: one row), %9 bytes of the gate table
-    E.e(f"s_mov_b64 {sr(S['GBASE'], 2)}, %7")
-    E.e(f"s_mov_b32 {sr(S['GLD'])}, %8")
-    E.e(f"s_mov_b32 {sr(S['GD'] + 2)}, %9")
     E.e(f"s_mov_b32 {sr(S['BD'] + 2)}, {C.nb * 2 * 32 * 2}")
-    if FP8:      # %10 base of the row scales (fp32, one per activation row), %11 M - 1
+    if FP8:
         assert not stamp, "the fp8 form keeps its scale base in the stamp counters' SGPRs"
-        E.e(f"s_mov_b64 {sr(S_SCB, 2)}, %10")
-        E.e(f"s_mov_b32 {sr(S_MLAST)}, %11")
     end = E.label("pend")
     tile_loop = E.label("ptile")
     nodma = E.label("pnodma")
@@ -659,24 +865,36 @@ def emit_program(E, C, stamp, budget, first):
         E.e("s_waitcnt lgkmcnt(0)")
         E.e(f"s_mov_b32 {sr(T_START)}, {sr(S['TMP64'])}")
         E.e(f"s_mov_b32 {sr(S['ST1'])}, {sr(S['TMP64'])}")
-    emit_load_record(E, "A")
+    if tail:      # most launches have no 64-column pieces at all: one scalar load instead of a cursor round trip
+        E.e(f"s_load_dwordx4 {sr(S['REC'], 4)}, {sr(S['KARG'], 2)}, {K_QD}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_mov_b32 {sr(S['TMP0'])}, {K_PLAN + 32 + 8}")
+        E.e(f"s_cmp_lt_u32 {sr(S['XHOME'])}, {sr(S['REC'] + 1)}")
+        E.e(f"s_cselect_b32 {sr(S['TMP0'])}, {K_PLAN + 8}, {sr(S['TMP0'])}")
+        E.e(f"s_load_dword {sr(S['TMP0'])}, {sr(S['KARG'], 2)}, {sr(S['TMP0'])}")
+        E.e("s_waitcnt lgkmcnt(0)")
+        E.e(f"s_cmp_eq_u32 {sr(S['TMP0'])}, 0")
+        E.e(f"s_cbranch_scc1 {end}")
+    emit_grab_sync(E, tail)
+    emit_make_record(E, tail)
     E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
     E.e(f"s_cbranch_scc1 {end}")
     emit_dma_k0(E, C)
-    emit_load_record(E, "B")
+    emit_load_record_b(E)
     emit_tile_prefetch(E, C)
     E.e(f"s_waitcnt vmcnt({N_PREFETCH(C)})")        # the k-slice (and the L2 prefetches behind it) has landed; the bias / gate words may still be on their way
     E.e("s_barrier")
     E.e(f"{tile_loop}:")
+    emit_grab_issue(E, tail)                          # the NEXT unit: its index travels while this tile's k-loop runs
     if stamp:
         emit_stamp(E, ACC_W)
     emit_kloop(E, C, budget)
     if stamp:
         emit_stamp(E, ACC_K)
-    # next tile: its record (part A: operand descriptors) and the LDS-DMA of its first k-slice go out BEFORE the epilogue of the
-    # current tile, whose output / bias / gate descriptors (part B) stay those of the current tile until the epilogue is through
-    E.e(f"s_add_u32 {sr(S['TI'])}, {sr(S['TI'])}, 1")
-    emit_load_record(E, "A")
+    # next unit: its record (operand descriptors) and the LDS-DMA of its first k-slice go out BEFORE the epilogue of the current tile,
+    # whose output / bias / gate descriptors (emit_load_record_b) stay those of the current tile until the epilogue is through
+    emit_grab_read(E)
+    emit_make_record(E, tail)
     E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
     E.e(f"s_cbranch_scc1 {nodma}")
     emit_dma_k0(E, C)
@@ -686,21 +904,49 @@ def emit_program(E, C, stamp, budget, first):
         emit_stamp(E, ACC_E)
     E.e(f"s_cmp_eq_u32 {sr(S['REC'] + 10)}, 0")
     E.e(f"s_cbranch_scc1 {end}")
-    emit_load_record(E, "B")
+    emit_load_record_b(E)
     emit_tile_prefetch(E, C)
     E.e("s_barrier")                                 # every wave has waited for its LDS-DMA pieces inside the epilogue
     E.e(f"s_branch {tile_loop}")
     E.e(f"{end}:")
     E.e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E.e("s_barrier")                                 # nobody is still inside this body's LDS when the next one (or the stamp dump) starts
-    E.e(f"s_add_u32 {sr(S['TI'])}, {sr(S['TI'])}, 1")            # past the terminator
+
+
+def emit_exit(E):
+    """The last workgroup to get here (done counter, device scope) puts the cursors back to zero for the next launch on this stream."""
+    skip = E.label("exitskip")
+    E.e(f"s_cmp_lg_u32 {sr(S['WAVE'])}, 0")
+    E.e(f"s_cbranch_scc1 {skip}")
+    E.e(f"s_load_dwordx2 {sr(S['TMP64'], 2)}, {sr(S['KARG'], 2)}, {K_CURS}")
+    E.e(f"s_load_dword {sr(S['TMP0'])}, {sr(S['KARG'], 2)}, {K_DIMS1 + 28}")       # grid
+    E.e(f"v_mov_b32 {vr(0)}, 64")                                                  # byte offset of the done counter
+    E.e(f"v_mov_b32 {vr(1)}, 1")
+    E.e("s_waitcnt lgkmcnt(0)")
+    E.e("s_mov_b64 exec, 1")
+    E.e(f"global_atomic_add {vr(1)}, {vr(0)}, {vr(1)}, {sr(S['TMP64'], 2)} sc0 sc1")
+    E.e("s_waitcnt vmcnt(0)")
+    E.e(f"v_readfirstlane_b32 {sr(S['TMP1'])}, {vr(1)}")
+    E.e("s_mov_b64 exec, -1")
+    E.e(f"s_add_u32 {sr(S['TMP1'])}, {sr(S['TMP1'])}, 1")
+    E.e(f"s_cmp_lg_u32 {sr(S['TMP1'])}, {sr(S['TMP0'])}")
+    E.e(f"s_cbranch_scc1 {skip}")
+    E.e(f"v_mbcnt_lo_u32_b32 {vr(0)}, -1, 0")                                      # lanes 0..16: one cursor word each (16 cursors + the counter)
+    E.e(f"v_lshlrev_b32 {vr(0)}, 2, {vr(0)}")
+    E.e(f"v_mov_b32 {vr(1)}, 0")
+    E.e("s_mov_b64 exec, 0x1ffff")
+    E.e(f"global_store_dword {vr(0)}, {vr(1)}, {sr(S['TMP64'], 2)} sc0 sc1")
+    E.e("s_waitcnt vmcnt(0)")
+    E.e("s_mov_b64 exec, -1")
+    E.e(f"{skip}:")
 
 
 def generate(nb, stamp, budget, tail=0):
     E = Emitter()
-    emit_program(E, Cfg(nb), stamp, budget, True)
-    if tail:      # the tiles of the last, partly filled round, cut into 256 x tail*64 pieces (the table's second list)
-        emit_program(E, Cfg(tail), stamp, budget, False)
+    emit_program(E, Cfg(nb), stamp, budget, True, False)
+    if tail:      # the tiles of the last, partly filled round, cut into 256 x tail*64 pieces (the second list)
+        emit_program(E, Cfg(tail), stamp, budget, False, True)
+    emit_exit(E)
     if stamp:      # per wave: {kloop, epilogue, wait cycles, records passed, total cycles, total 100 MHz ticks} -> LDS table area (dead now)
         E.e(f"s_memtime {sr(S['TMP64'], 2)}")
         E.e("s_waitcnt lgkmcnt(0)")
@@ -709,7 +955,7 @@ def generate(nb, stamp, budget, tail=0):
         E.e("s_waitcnt lgkmcnt(0)")
         E.e(f"s_sub_u32 {sr(R_START)}, {sr(S['TMP64'])}, {sr(R_START)}")
         E.e("s_barrier")
-        for n, r in enumerate((ACC_K, ACC_E, ACC_W, S["TI"], T_START, R_START)):
+        for n, r in enumerate((ACC_K, ACC_E, ACC_W, S["NTILES"], T_START, R_START)):
             E.e(f"v_mov_b32 {vr(8 + n)}, {sr(r)}")
         E.e(f"v_mov_b32 {vr(14)}, 0")
         E.e(f"v_mov_b32 {vr(15)}, 0")

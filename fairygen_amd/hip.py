@@ -51,7 +51,7 @@ _SIGNATURES = {
     "fg_gated_gelu_bf16": [_vp, _vp, _vp, _i64, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["fg_version", "fg_last_error", "fg_conv_packed_bytes", "fg_attn_workspace_bytes", "fg_attn_split_choice",
-                                                   "fg_conv_tile_choice", "fg_gemm_workspace_bytes"])
+                                                   "fg_conv_tile_choice", "fg_gemm_workspace_bytes", "fg_gemm_debug_grid"])
 
 
 class HipLibraryError(RuntimeError):
@@ -82,6 +82,8 @@ def load():
     lib.fg_conv_tile_choice.argtypes = [_i32] * 4
     lib.fg_gemm_workspace_bytes.restype = ctypes.c_int64
     lib.fg_gemm_workspace_bytes.argtypes = [_i64] * 3
+    lib.fg_gemm_debug_grid.restype = ctypes.c_int
+    lib.fg_gemm_debug_grid.argtypes = [_i32]
     lib.fg_attn_split_choice.restype = ctypes.c_int
     lib.fg_attn_split_choice.argtypes = [_i32, _i64, _i64, _i32, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     for name, argtypes in _SIGNATURES.items():

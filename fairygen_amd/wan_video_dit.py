@@ -60,6 +60,7 @@ def gemm_bias_tuned(x, weight, bias):
 # so a denoise step launches no library GEMM inside the blocks; "fused": qkv and ffn.0 (+ GELU in the hipBLASLt epilogue) stay on the
 # library (round 2's default); "fused-ffn2": ffn.2 as well; "lib": everything on hipBLASLt.  Measurements: DESIGN.md §5.
 GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "all")
+GEMM_MIN_TILES = int(os.environ.get("FAIRYGEN_GEMM_MIN_TILES", "64"))      # experiments: 512 = round 2's "two rounds of the CUs" rule
 FP8_FOLD = os.environ.get("FAIRYGEN_FP8_FOLD", "1") != "0"      # fp8 mode: norm kernels emit (e4m3 rows, scales) directly
 FP8_GEMM = os.environ.get("FAIRYGEN_FP8_GEMM", "own")           # fp8 mode: "own" = fg_gemm_fp8_bf16, "lib" = torch._scaled_mm (hipBLASLt)
 
@@ -69,7 +70,7 @@ def own_gemm_ok(rows, n, k):
     launch.  Round 2 asked for two rounds of the CUs (512 tiles); measured at the 8- / 4- / 2-rank shard sizes (3 410 / 6 820 / 13 640
     rows) the kernel is within 5 % of the library on every shape with one round or less, 1.6x faster on ffn.2 (K = 14 336:
     1 154 vs 739 TFLOP/s at 3 410 rows), and the fused residual store replaces a separate pass."""
-    return GEMM_BACKEND != "lib" and n % 256 == 0 and k % 128 == 0 and ((rows + 255) // 256) * (n // 256) >= 64
+    return GEMM_BACKEND != "lib" and n % 256 == 0 and k % 128 == 0 and ((rows + 255) // 256) * (n // 256) >= GEMM_MIN_TILES
 
 
 def gemm_bias_own(x, weight, bias):
@@ -79,6 +80,11 @@ def gemm_bias_own(x, weight, bias):
 def gemm_bias_gelu_own(x, weight, bias):
     """ffn.0 + nn.GELU(approximate='tanh') (models/wan_video_dit.py:208): GELU on the bf16-rounded Linear output in the GEMM's store."""
     return hip.gemm_epilogue(x, weight, bias, act="gelu_tanh")
+
+
+def gemm_fp8_own(xq, scale_a, w8, bias):
+    """fp8_linear's matmul on the e4m3 form of the persistent kernel: (rows, K) e4m3 x (N, K) e4m3 -> (1, rows, N) bf16."""
+    return hip.gemm_fp8(xq, scale_a, w8, bias, lead_shape=(1, xq.shape[0]))
 
 
 def gemm_residual(x, a, weight, bias, mod=None, gate_idx=None):
@@ -254,7 +260,7 @@ class WanModel(nn.Module):
         MFMA kernel (fg_gemm_fp8_bf16), or — FAIRYGEN_FP8_GEMM=lib, and for shapes the kernel does not take — the library call itself."""
         n = w8.shape[0]
         if FP8_GEMM == "own" and n % 256 == 0 and xq.shape[1] % 256 == 0:
-            return hip.gemm_fp8(xq, scale_a, w8, bias, lead_shape=(1, xq.shape[0]))
+            return gemm_fp8_own(xq, scale_a, w8, bias)
         key = (n, xq.device)
         if key not in self._ones:
             self._ones[key] = torch.ones((1, n), dtype=torch.float32, device=xq.device)

@@ -91,7 +91,7 @@ int fg_residual_ln_fp8_bf16(const void* x, const void* y, const void* gate, void
  * with the bf16 rounding points of the reference's separate ops.  a has leading dimension lda, c ldc (elements); w is the row-major
  * (out_features, in_features) weight.  gate: a table of gate_rows (1 or 2) rows of N values, row stride gate_ld elements; with 2 rows,
  * output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the others row 1.  N %% 256 == 0, K %% 128 == 0.
- * Persistent kernel: one workgroup per CU of the device walks a list of 256 x 256 output tiles (csrc/gen_gemm_p.py).  The tiles left
+ * Persistent kernel: one workgroup per CU of the device takes 256 x 256 output tiles from a per-XCD cursor (csrc/gen_gemm_p.py).  The tiles left
  * over after the last whole round of the CUs are finished as pieces: with `workspace` (fg_gemm_workspace_bytes(M, N, K) bytes of
  * device memory, 16-byte aligned; may be NULL) and K >= 6144 cut along K into fp32 partial sums that a second small kernel adds in k
  * order before the same epilogue — those elements' fp32 summation is then grouped per piece (fixed for a given shape and device; every
@@ -100,6 +100,12 @@ int64_t fg_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int fg_gemm_epilogue_bf16(const void* a, int64_t lda, const void* w, const void* bias, void* c, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
                           int64_t first_rows, void* workspace, fg_stream_t stream);
+
+/* Diagnostics for the persistent GEMM's unit scheduler: launch only `workgroups` workgroups (a multiple of the XCD count, at most one
+ * per CU; 0 = one per CU again).  The units of a launch are fixed by the shape; workgroups take them from per-XCD cursors, so the result
+ * is bit-identical with any number of workgroups — as when other kernels (RCCL) hold some CUs.  The library keeps 256 bytes of device
+ * memory per (device, stream) it has launched a GEMM on (the cursors; cleared by the last workgroup of every launch). */
+int fg_gemm_debug_grid(int workgroups);
 
 /* The matmul of AutoWrappedLinear.fp8_linear (core/vram/layers.py:343-357: torch._scaled_mm(x_fp8, w_fp8.T, scale_a (rows, 1),
  * scale_b = ones (1, out), bias, out_dtype = bf16)) on the same persistent kernel with e4m3 operands (OCP float8_e4m3fn,

@@ -194,6 +194,37 @@ def test_gemm_epilogue_ksplit(hip, M, K, N):
     assert torch.equal(hip.gemm_epilogue(dwide[..., 64:64 + K], dw, db), hip.gemm_epilogue(dwide[..., 64:64 + K].contiguous(), dw, db))
 
 
+@pytest.mark.parametrize("M,K,N", [(4200, 512, 4096), (600, 14336, 3072), (700, 256, 768), (27280, 256, 3072)])
+def test_gemm_unit_scheduler(hip, M, K, N):
+    """The units of a launch (whole tiles, k-range pieces, 64-column pieces) are fixed by the shape; which workgroup computes which is
+    decided by per-XCD cursors at run time.  With fewer workgroups than CUs (fg_gemm_debug_grid: what a CU held by another stream's kernel
+    looks like) every unit is still computed, by the workgroups that are there: results bit-identical to the full grid's, launch after
+    launch (the last workgroup of a launch clears the cursors), in both operand types and with the fused epilogues."""
+    lib = hip.load()
+    x, w, b = seeded((1, M, K), 161), seeded((N, K), 162, scale=0.05), seeded((N,), 163, scale=0.2)
+    dx, dw, db = dev(x), dev(w), dev(b)
+    res = dev(seeded((1, M, N), 164))
+    mod = hip.ModTable(dev(seeded((2, 6, N), 165)), 130)
+    xq, sc = hip.fp8_quant_rows(dx)
+    w8 = dw.to(torch.float8_e4m3fn)
+
+    def run():
+        return (hip.gemm_epilogue(dx, dw, db), hip.gemm_epilogue(dx, dw, db, out=res.clone(), residual=True, mod=mod, gate_idx=2),
+                hip.gemm_epilogue(dx, dw, db, act="gelu_tanh"), hip.gemm_fp8(xq, sc, w8, db) if K % 256 == 0 else None)
+    want = run()
+    assert torch.isfinite(want[0].float()).all()
+    try:
+        for grid in (200, 128, 8, 256, 64):
+            assert lib.fg_gemm_debug_grid(grid) == 0
+            for rep in range(2):
+                got = run()
+                for i, (g, wnt) in enumerate(zip(got, want)):
+                    assert wnt is None or torch.equal(g, wnt), f"grid {grid}, launch {rep}, output {i}"
+    finally:
+        lib.fg_gemm_debug_grid(0)
+    assert all(wnt is None or torch.equal(g, wnt) for g, wnt in zip(run(), want))
+
+
 @pytest.mark.parametrize("M,K,N", [(700, 3072, 768),        # 9 tiles: 64-column pieces (second body); 24 k-steps of 128 e4m3
                                    (4200, 1024, 4096),      # 272 tiles: a full round + cut tail, ragged last rows, 8 k-steps
                                    (600, 14336, 3072)])     # ffn.2's reduction: 112 k-steps, left-over tiles as k-range pieces + reduce kernel
