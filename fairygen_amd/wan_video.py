@@ -248,16 +248,19 @@ class WanVideoUnit_CfgMerger(PipelineUnit):
         self.concat_tensor_names = ["context"]
 
     def process(self, pipe, inputs_shared, inputs_posi, inputs_nega):
-        if not inputs_shared.get("cfg_merge"):
-            return inputs_shared, inputs_posi, inputs_nega
-        for name in self.concat_tensor_names:
-            tensor_posi, tensor_nega, tensor_shared = inputs_posi.get(name), inputs_nega.get(name), inputs_shared.get(name)
-            if tensor_posi is not None and tensor_nega is not None:
-                inputs_shared[name] = torch.concat((tensor_posi, tensor_nega), dim=0)
-            elif tensor_shared is not None:
-                inputs_shared[name] = torch.concat((tensor_shared, tensor_shared), dim=0)
-        inputs_posi.clear()
-        inputs_nega.clear()
+        if inputs_shared.get("cfg_merge"):
+            # a per-branch tensor becomes a (2, ...) batch [positive, negative]; one that is already shared is doubled so that it lines up
+            # with the batched ones; everything else the branches carried is dropped (the loop makes one call without branch inputs)
+            merged = {}
+            for name in self.concat_tensor_names:
+                pair = (inputs_posi.get(name), inputs_nega.get(name))
+                if pair[0] is None or pair[1] is None:
+                    pair = (inputs_shared.get(name),) * 2
+                if pair[0] is not None:
+                    merged[name] = torch.cat(pair, dim=0)
+            inputs_shared.update(merged)
+            inputs_posi.clear()
+            inputs_nega.clear()
         return inputs_shared, inputs_posi, inputs_nega
 
 
@@ -663,7 +666,8 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
         if tea_cache is not None:
             raise NotImplementedError("TeaCache is per CFG branch; the merged call has none (the reference drops it too)")
         outs = []
-        prefix = {} if (CFG_SHARE_PREFIX and sliding_window_size is None) else None      # the elements differ only in their context
+        # the elements differ only in their context: block 0's self-attention half is shared — between exactly two (one producer, one consumer)
+        prefix = {} if (CFG_SHARE_PREFIX and sliding_window_size is None and context.shape[0] == 2) else None
         for b in range(context.shape[0]):
             outs.append((yield from model_fn_wan_video_steps(
                 dit, latents=latents, timestep=timestep, context=context[b:b + 1], sequence_shard=sequence_shard,
@@ -703,7 +707,16 @@ def model_fn_wan_video_steps(dit, latents=None, timestep=None, context=None, fus
     # block in forward_tokens_steps — is kept for the denoise loop that owns kv_cache (keyed by the prompt tensor)
     kv = None
     if kv_cache is not None and sliding_window_size is None:
-        kv = kv_cache.setdefault((context.data_ptr(), tuple(context.shape), context._version), {})
+        # an entry belongs to ONE prompt tensor object at ONE version (it keeps the tensor alive, so its address cannot be reused while the
+        # entry exists); a loop has two prompts, so a handful of entries is a caller re-materialising its context every step: the oldest goes
+        entries = kv_cache.setdefault("entries", [])
+        base = context._base if context._base is not None else context          # the merged call passes views context[b:b+1] of one tensor
+        ident = (context.storage_offset(), tuple(context.shape), tuple(context.stride()), context._version)
+        kv = next((e["kv"] for e in entries if e["base"] is base and e["ident"] == ident), None)
+        if kv is None:
+            kv = {}
+            entries.append({"base": base, "ident": ident, "kv": kv})
+            del entries[:-4]
     if kv is not None and "ctx" in kv:
         ctx = kv["ctx"]
     else:

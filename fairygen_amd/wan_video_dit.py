@@ -60,7 +60,7 @@ def gemm_bias_tuned(x, weight, bias):
 # so a denoise step launches no library GEMM inside the blocks; "fused": qkv and ffn.0 (+ GELU in the hipBLASLt epilogue) stay on the
 # library (round 2's default); "fused-ffn2": ffn.2 as well; "lib": everything on hipBLASLt.  Measurements: DESIGN.md §5.
 GEMM_BACKEND = os.environ.get("FAIRYGEN_GEMM", "all")
-GEMM_MIN_TILES = int(os.environ.get("FAIRYGEN_GEMM_MIN_TILES", "64"))      # experiments: 512 = round 2's "two rounds of the CUs" rule
+GEMM_MIN_TILES = 64      # round 2 asked for two rounds of the CUs (512 tiles); see own_gemm_ok
 FP8_FOLD = os.environ.get("FAIRYGEN_FP8_FOLD", "1") != "0"      # fp8 mode: norm kernels emit (e4m3 rows, scales) directly
 FP8_GEMM = os.environ.get("FAIRYGEN_FP8_GEMM", "own")           # fp8 mode: "own" = fg_gemm_fp8_bf16, "lib" = torch._scaled_mm (hipBLASLt)
 
@@ -465,9 +465,18 @@ class WanModel(nn.Module):
                 lin = lambda t, j, bias, act=None: self._scaled_linear(*(t if isinstance(t, tuple) else hip.fp8_quant_rows(t, act)), w8[j], bias)      # noqa: E731
             own = fp8 is None and not hot and mod.mod_rows in (1, 2)
             if cfg_prefix is not None and i == 0 and "owner" in cfg_prefix:
+                if cfg_prefix.get("taken"):
+                    raise RuntimeError("cfg_prefix is shared by exactly two forwards of one step (one computes block 0's self-attention half, "
+                                       "one takes it): a third consumer of the same dict")
+                spins = 0
                 while "x_sa" not in cfg_prefix:      # the other branch is inside block 0's self-attention: let it run
+                    spins += 1
+                    if spins > 100000:
+                        raise RuntimeError("cfg_prefix: the forward that owns block 0's self-attention half never published it (the two "
+                                           "forwards of a step must be advanced in turns, or run one after the other)")
                     yield i
                 x = cfg_prefix.pop("x_sa")
+                cfg_prefix["taken"] = True
                 h = hip.ln_affine(x, blk.norm3.weight, blk.norm3.bias, eps)
                 reuse = True
             else:

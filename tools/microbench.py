@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--rows", type=int, default=27280)
     ap.add_argument("--interleaved", action="store_true")
     ap.add_argument("--per-head", action="store_true")
+    ap.add_argument("--attn-scale", default="pow2", choices=["pow2", "model", "both"],
+                    help="pow2: the scale the pipeline passes for self-attention (2^-3 / log2 e: the kernel's pre-multiplied form); model: 1/sqrt(d) (plain form)")
     a = ap.parse_args()
     hip.load()
     dev = "cuda"
@@ -66,9 +68,11 @@ def main():
             print(f"attn per-head layout nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
             return
         out = torch.empty((1, a.nq, c), dtype=torch.bfloat16, device=dev)
-        med, mn = timeit(lambda: hip.attention(q, k, v, a.heads, out=out), a.iters)
         fl = 4.0 * a.nq * a.nkv * c
-        print(f"attn nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
+        for form in (("pow2", "model") if a.attn_scale == "both" else (a.attn_scale,)):
+            scale = hip.pow2_softmax_scale(128)[0] if form == "pow2" else None
+            med, mn = timeit(lambda: hip.attention(q, k, v, a.heads, out=out, scale=scale), a.iters)
+            print(f"attn ({form} scale) nq={a.nq} nkv={a.nkv} H={a.heads}: median {med:.3f} ms ({fl / med / 1e9:.1f} TFLOP/s), min {mn:.3f} ms ({fl / mn / 1e9:.1f})")
     elif a.what == "conv":
         x = rnd(a.t + a.kt - 1, a.h, a.w, a.cin)
         w = rnd(a.cout, a.cin, a.kt, a.ks, a.ks) * (a.cin * a.kt * a.ks * a.ks) ** -0.5
