@@ -291,6 +291,7 @@ def main():
     ap.add_argument("--sliding-window", default="", metavar="SIZE,STRIDE",
                     help="the reference's APPROXIMATE sliding-window mode (latent frames per window, stride); with --layout "
                          "cfg1-windows the windows are dealt to the ranks.  Never the headline configuration")
+    ap.add_argument("--gemm-grid", type=int, default=0, help="experiment: launch the persistent GEMM with this many workgroups (fg_gemm_debug_grid; reported in config)")
     ap.add_argument("--layout", default=os.environ.get("FAIRYGEN_PARALLEL", "auto"), choices=("auto",) + LAYOUTS,
                     help="N>1: how the ranks are used (auto: time every candidate for one step in the warm-up, keep the fastest)")
     args = ap.parse_args()
@@ -300,6 +301,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
+    if args.gemm_grid:
+        from fairygen_amd import hip as _hip
+        _hip.load().fg_gemm_debug_grid(args.gemm_grid)
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)      # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -444,6 +448,8 @@ def main():
                                   "fused into ffn.2's row quantisation" if args.linear_dtype == "fp8" else
                                   "hipBLASLt epilogue" if args.gelu_epilogue else "fg_act_bf16 kernel")
         line["config"]["dit_gemm_backend"] = _wd.GEMM_BACKEND + " (FAIRYGEN_GEMM: which Linears run on gemm_p_kernel instead of hipBLASLt; 'all' = every Linear of the blocks)"
+        if args.gemm_grid:
+            line["config"]["EXPERIMENT_gemm_workgroups"] = args.gemm_grid
         if args.linear_dtype == "fp8":
             line["config"]["fp8_gemm"] = _wd.FP8_GEMM + " (FAIRYGEN_FP8_GEMM: own = fg_gemm_fp8_bf16, lib = torch._scaled_mm)"
         line["config"]["attention_scale"] = ("2^-3 / log2(e) with 1.0201 folded into q's RoPE table: exact pre-multiplied form of attn_fwd_w4_kernel"
