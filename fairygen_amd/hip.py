@@ -321,8 +321,10 @@ _gemm_workspace = {}      # (device, stream) -> scratch for the k-split pieces o
 
 
 def _gemm_ws(x, m, n, k_bytes, workspace):
-    """The k-split scratch, only where fg_gemm_* would use it (at least 96 k-steps of 128 operand bytes)."""
-    need = load().fg_gemm_workspace_bytes(m, n, k_bytes) if workspace and k_bytes // 128 >= 96 else 0
+    """The k-split scratch, only where fg_gemm_* would use it: at least 96 k-steps of 128 operand bytes, or at most 8 rounds of tiles per CU
+    (launch_gemm in csrc/dit_gemm.hip; 256 CUs assumed here — a spare allocation on other devices, never a missing one)."""
+    tiles = ((m + 255) // 256) * (n // 256)
+    need = load().fg_gemm_workspace_bytes(m, n, k_bytes) if workspace and (k_bytes // 128 >= 96 or tiles <= 8 * 256) else 0
     if need <= 0:
         return None
     key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)      # concurrent streams must not share scratch

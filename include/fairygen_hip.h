@@ -93,7 +93,7 @@ int fg_residual_ln_fp8_bf16(const void* x, const void* y, const void* gate, void
  * output rows < first_rows use row 0 (the first latent frame's t = 0 modulation), the others row 1.  N %% 256 == 0, K %% 128 == 0.
  * Persistent kernel: one workgroup per CU of the device takes 256 x 256 output tiles from a per-XCD cursor (csrc/gen_gemm_p.py).  The tiles left
  * over after the last whole round of the CUs are finished as pieces: with `workspace` (fg_gemm_workspace_bytes(M, N, K) bytes of
- * device memory, 16-byte aligned; may be NULL) and K >= 6144 cut along K into fp32 partial sums that a second small kernel adds in k
+ * device memory, 16-byte aligned; may be NULL) and K >= 6144 or at most 8 rounds of tiles per CU cut along K into fp32 partial sums that a second small kernel adds in k
  * order before the same epilogue — those elements' fp32 summation is then grouped per piece (fixed for a given shape and device; every
  * other element is one full-K accumulation in k order); otherwise cut into 64-column pieces, every element accumulated in k order. */
 int64_t fg_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
@@ -112,7 +112,7 @@ int fg_gemm_debug_grid(int workgroups);
  * v_mfma_f32_32x32x64_f8f6f4): y = bf16((acc * scale_a[row]) + bias[col]) — one fp32 rounding per operation, as the library op —
  * followed by the epilogue `mode` of fg_gemm_epilogue_bf16 (0, 2, 3, 4) on y.  a_fp8: (M, K) bytes with leading dimension lda,
  * w_fp8: (N, K) row-major, scale_a: M fp32 values (fg_fp8_quant_rows_bf16 / the fp8-output norm kernels produce a_fp8 and scale_a).
- * N %% 256 == 0, K %% 256 == 0, lda %% 16 == 0; workspace as above (taken for K >= 12288). */
+ * N %% 256 == 0, K %% 256 == 0, lda %% 16 == 0; workspace as above (taken for K >= 12288 or at most 8 rounds of tiles per CU). */
 int fg_gemm_fp8_bf16(const void* a_fp8, int64_t lda, const float* scale_a, const void* w_fp8, const void* bias, void* c, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int mode, const void* gate, int64_t gate_rows, int64_t gate_ld,
                      int64_t first_rows, void* workspace, fg_stream_t stream);

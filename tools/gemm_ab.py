@@ -1,6 +1,6 @@
 """The hand-scheduled DiT GEMMs against F.linear (hipBLASLt) on the DiT shapes: correctness + interleaved timing.
 
-    python tools/gemm_ab.py [--m 27280] [--only p] [--only p|fp8] [--stamp-lib-p path]
+    python tools/gemm_ab.py [--m 27280] [--only p|fp8] [--stamp-lib-p path]
 
   p  : fg_gemm_epilogue_bf16, the persistent form (one workgroup per CU, tile list, 256x256 tiles), mode 0, its residual modes
        (2: x + gate*y, 3: x + y) against the library GEMM followed by fg_gate_residual_bf16, and mode 4 (GELU) against the library's
@@ -125,15 +125,18 @@ def main():
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             for _ in range(3):
                 stamp_p.fg_gemm_epilogue_bf16(x.data_ptr(), k, w.data_ptr(), b.data_ptr(), o2.data_ptr(), n, a.m, n, k, 0, None, 1, n, 0, wsp.data_ptr(), st)
-            buf = np.zeros((256, 4, 8), dtype=np.uint32)
+            buf = np.zeros((256, 4, 8), dtype=np.uint32)      # one workgroup per CU (256 on MI355X)
             stamp_p.fg_gemm_stamp_read(buf.ctypes.data_as(ctypes.c_void_p), st)
             w0 = buf[:, 0, :].astype(np.float64)          # wave 0 of every workgroup: kloop, epilogue, wait, tiles, total, ticks
-            tiles = np.maximum(w0[:, 3] - 2, 1)          # records passed, minus the two list terminators
+            tiles = np.maximum(w0[:, 3], 1)              # units this workgroup took from the cursors
             clk = np.median(w0[:, 4] / np.maximum(w0[:, 5], 1) * 100)
             print(f"   p stamp ({'equal' if torch.equal(o2, outp) else 'DIFFERENT'} output): tiles/CU {tiles.min():.0f}-{tiles.max():.0f}; per tile: "
                   f"k-loop {np.median(w0[:, 0] / tiles):.0f} ({np.median(w0[:, 0] / tiles) / (k // 64):.0f} per 64-k step), epilogue "
                   f"{np.median(w0[:, 1] / tiles):.0f}, wait {np.median(w0[:, 2] / tiles):.0f} cycles; kernel {np.median(w0[:, 4]):.0f} cycles "
                   f"(max {w0[:, 4].max():.0f}), clock {clk:.0f} MHz; sum of parts {np.median((w0[:, 0] + w0[:, 1] + w0[:, 2])):.0f}", flush=True)
+            tot = np.sort(w0[:, 4])
+            print(f"      per-CU kernel cycles: p10 {tot[25]:.0f} p50 {tot[128]:.0f} p90 {tot[230]:.0f} p99 {tot[253]:.0f} max {tot[-1]:.0f}; units per CU histogram "
+                  f"{dict(zip(*np.unique(w0[:, 3].astype(int), return_counts=True)))}; ideal (sum of all CUs / 256) {w0[:, 4].sum() / 256:.0f}", flush=True)
 
 
 if __name__ == "__main__":
