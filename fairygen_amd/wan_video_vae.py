@@ -197,7 +197,9 @@ class VideoVAE38_(nn.Module):
         self._conv_states = None
         self._down_cache = {}
         self.z_dim = z_dim
-        self.max_chunk_group = 4      # latent frames per decoder call after the first (1 = the reference's chunking)
+        # latent frames per decoder call after the first (1 = the reference's chunking; identical arithmetic per output for any value).  8 is what
+        # the conv kernel's 32-bit offsets allow at the (30, 52) tile; measured on it: 4 -> 808 ms, 6 -> 790, 8 -> 786 (fewer, larger launches)
+        self.max_chunk_group = 8
 
     # ------------------------------------------------------------------ weight preparation
     def invalidate_packed(self):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--h", type=int, default=30)
     ap.add_argument("--w", type=int, default=52)
     ap.add_argument("--frames", type=int, default=31)
+    ap.add_argument("--group", type=int, default=0, help="latent frames per decoder call after the first (0 = the model's default)")
+    ap.add_argument("--top", type=int, default=1000, help="rows of the per-shape table to print")
     a = ap.parse_args()
     args = argparse.Namespace(layers=2, no_lora=True, height=704, width=1280, frames=121)
     pipe, _ = bench.build_pipeline(args, "cuda:0")
@@ -43,6 +45,8 @@ def main():
     wrap("vae_rmsnorm_silu", lambda x, g, silu=True, out=None: (tuple(x.shape),))
     wrap("dupup3d_add", lambda x, main, *r, **kw: (tuple(x.shape), tuple(main.shape)))
     wrap("vae_unpatchify", lambda x, *r, **kw: (tuple(x.shape),))
+    if a.group:
+        pipe.vae.model.max_chunk_group = a.group
     with torch.no_grad():
         pipe.vae.model.decode(z[:, :, :2, :8, :8].contiguous(), pipe.vae.scale)      # warm-up / weight packing
         records.clear()
@@ -65,7 +69,7 @@ def main():
         k = (name, shape)
         agg[k][0] += 1; agg[k][1] += ms; agg[k][2] += fl
     print(f"decode of a (1,48,{a.frames},{a.h},{a.w}) tile: {total:.1f} ms; timed calls {sum(v[1] for v in agg.values()):.1f} ms")
-    for (name, shape), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    for (name, shape), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
         tf = f"{fl / ms / 1e9:7.0f} TF/s" if fl else ""
         print(f"{ms:8.2f} ms {ms / total * 100:5.1f}%  x{n:4d}  {name:18s} {shape} {tf}")
 
