@@ -111,7 +111,8 @@ def test_fused_residual_norms(hip):
 
 @pytest.mark.parametrize("M,K,N", [(700, 256, 768),       # 9 tiles: every one a 64-column tail piece (second body, ring of 3)
                                    (4200, 512, 4096),     # 272 tiles: one full round of 256-column tiles + cut tail, ragged last rows
-                                   (10500, 128, 2048)])   # 336 tiles: left-over tiles NOT cut (10 per XCD), K = one step pair, 4 rows in the last row tile
+                                   (10500, 128, 2048),    # 336 tiles: left-over tiles NOT cut (10 per XCD), K = one step pair, 4 rows in the last row tile
+                                   (3410, 3072, 3072)])   # the 1/8 token shard of the headline clip: 168 tiles on 256 CUs (o / cross-q / cross-o of config 4)
 def test_gemm_epilogue(hip, M, K, N):
     """fg_gemm_epilogue_bf16 (persistent MFMA GEMM, nn.Linear of the DiT blocks: models/wan_video_dit.py:130-133,208-209): error to
     the fp32 product <= 2x the error of the reference's own bf16 op (CPU F.linear) + floor; the residual modes (GateModule :188-193,
@@ -157,7 +158,8 @@ def test_gemm_epilogue(hip, M, K, N):
 @pytest.mark.parametrize("M,K,N", [(4200, 6144, 4096),     # 272 tiles: one full round + 2 left-over tiles per XCD, k-split 16 ways; 104 rows in the last row tile
                                    (600, 14336, 3072),     # ffn.2's reduction length: 36 tiles = 4-5 per XCD, no full round, cut 8 / 6 ways
                                    (8300, 14336, 512),     # 66 tiles: 8-9 per XCD on 32 CUs, cut 4 / 3 ways (224 k-steps -> 75 + 75 + 74)
-                                   (66200, 6144, 256)])    # 259 tiles in one column: one left-over tile (32 pieces) on three XCDs, none on the others
+                                   (66200, 6144, 256),     # 259 tiles in one column: one left-over tile (32 pieces) on three XCDs, none on the others
+                                   (3410, 14336, 3072)])   # ffn.2 at the 1/8 token shard (config 4): 168 tiles, 21 per XCD — no piece fits: every tile whole
 def test_gemm_epilogue_ksplit(hip, M, K, N):
     """The k-split path of fg_gemm_epilogue_bf16 (K >= 6 144 with a workspace: the left-over tiles of an XCD's last round are computed as
     k-range pieces whose fp32 accumulators go to the workspace and are added in k order by gemm_reduce_kernel, csrc/dit_gemm.hip) — the
@@ -177,7 +179,8 @@ def test_gemm_epilogue_ksplit(hip, M, K, N):
         err = (t[0].cpu()[rows].float() - ref32).abs().max().item()
         assert err <= 2 * ref_err + 1e-3, f"gemm {M}x{K}x{N} ({name}): {err} vs reference bf16 error {ref_err}"
     assert_close_bf16(y, y_nows, 1.0, "k-split vs single accumulation", max_mismatch=0.02)
-    assert not torch.equal(y, y_nows), "the k-split path did not run (identical to the single-accumulation result)"
+    if M != 3410:      # (at 3 410 rows the plan has no k-range pieces: the two calls are the same computation)
+        assert not torch.equal(y, y_nows), "the k-split path did not run (identical to the single-accumulation result)"
     res = seeded((1, M, N), 144)
     first = M - 300                                            # the gate class changes inside the last rows (left-over tiles live there)
     table = seeded((2, 6, N), 145)
