@@ -72,6 +72,34 @@ def test_gemm_entry_point_validation_and_backend_policy():
         assert not wd.own_gemm_ok(27280, 128, 128) and not wd.own_gemm_ok(27280, 3072, 3000)
 
 
+def test_attention_scale_fold_is_host_arithmetic():
+    """The self-attention scale split: 1/sqrt(d) * log2(e) = 2^e * f with f in [1/sqrt2, sqrt2); scale' = 2^e / log2(e) is what the kernel
+    gets (its pre-multiplied form is exact for it), f goes into q's RoPE table; WanModel.attn_scale() turns the fold off whenever q must
+    stay as the reference rounds it (fp64 RoPE mode, fold_attn_scale = False, a replaced AttentionModule)."""
+    import math
+    from fairygen_amd.wan_video_dit import AttentionModule
+    scale, f = hip.pow2_softmax_scale(128)
+    assert abs(scale * math.log2(math.e) - 2.0 ** -3) < 1e-15 and abs(f - 1.0201394465) < 1e-9
+    assert abs(scale * f - 128 ** -0.5) < 1e-15
+    for d in (64, 96, 128, 256):
+        sc, ff = hip.pow2_softmax_scale(d)
+        assert math.log2(sc * math.log2(math.e)).is_integer() and 2 ** -0.5 <= ff < 2 ** 0.5 and abs(sc * ff - d ** -0.5) < 1e-15
+    m = WanModel(**synthetic.TINY_DIT_KWARGS)
+    assert m.attn_scale() == (scale, f)
+    tk, tq = m.rope_tables(2, 3, 4, "cpu")
+    assert tk.dtype == torch.float32 and tk.shape == (24, 64, 2) and torch.allclose(tq, tk * f, rtol=1e-6) and not torch.equal(tq, tk)
+    m.fold_attn_scale = False
+    assert m.attn_scale() == (None, 1.0) and m.rope_tables(2, 3, 4, "cpu")[0] is m.rope_tables(2, 3, 4, "cpu")[1]
+    m.fold_attn_scale, m.rope_mode = True, "f64"
+    assert m.attn_scale() == (None, 1.0) and m.rope_tables(2, 3, 4, "cpu")[0].dtype == torch.float64
+    m.rope_mode = "f32"
+
+    class Plugged(AttentionModule):
+        pass
+    m.blocks[0].self_attn.attn = Plugged(m.num_heads)
+    assert m.attn_scale() == (None, 1.0)          # a user-supplied attention module gets q exactly as the reference computes it
+
+
 def test_argument_validation_through_the_c_abi():
     lib = hip.load()
     rc = lib.fg_attn_fwd_bf16(None, 0, None, 0, None, 0, None, 1, 1, 1, 1, 128, 1.0, None, 0, None)
