@@ -1,6 +1,7 @@
 // HBM-bound VAE decode helpers (channels-last activations): RMS_norm(+SiLU), DupUp3D shortcut + add,
 // row softmax for the mid AttentionBlock, layout boundary kernels, tiled-decode feathering, uint8 frames.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -9,7 +10,15 @@ constexpr int kMaxVecV = 4;   // C <= 2048 per pixel row, one wave per pixel
 
 // F.normalize(x, dim=C) * sqrt(C) * gamma (+ SiLU): every op rounded to bf16 like the reference chain.
 // LPP lanes own one pixel (64: C <= 2048; 32: C <= 256, two pixels per wave so that no lane idles on the 256-channel
-// last stage, where this kernel is VALU-bound: ~35 VALU ops per element for the divisions, roundings and SiLU).
+// last stage, where this kernel is VALU-bound: the divisions, roundings and SiLU of every element).
+// a / b from r = rcp(b) (1 ulp) and one residual correction: q0 = a r, q = q0 + (a - b q0) r — within 1 fp32 ulp of the IEEE quotient (every result here
+// is rounded to bf16 next, 16 bits coarser), for ~3 VALU operations instead of the ~10 of the full division sequence: this kernel is VALU-bound
+// (measured 3.2 TB/s on the 256-channel stage with two IEEE divisions per element)
+__device__ __forceinline__ float div_by(float a, float b, float r) {
+    const float q0 = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0);
+}
+
 template <int LPP>
 __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                           bf16* __restrict__ out, int64_t pixels, int C, float sqrt_c,
@@ -34,6 +43,7 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16* __restrict
     for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (!live) return;
     const float denom = fmaxf(rbf(sqrtf(ss)), 1e-12f);
+    const float rdenom = __builtin_amdgcn_rcpf(denom);
 #pragma unroll
     for (int i = 0; i < kVec; ++i) {
         const int vi = lane + i * LPP;
@@ -42,8 +52,11 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16* __restrict
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float y = rbf(rbf(rbf(v[i][j] / denom) * sqrt_c) * (float)g[j]);
-                if (apply_silu) y = silu_f(y);
+                float y = rbf(rbf(rbf(div_by(v[i][j], denom, rdenom)) * sqrt_c) * (float)g[j]);
+                if (apply_silu) {      // y / (1 + exp(-y)), the quotient again by reciprocal + one correction step
+                    const float d = 1.0f + __expf(fminf(-y, 80.0f));      // finite d: rcp(inf) = 0 would turn the correction step into inf * 0
+                    y = div_by(y, d, __builtin_amdgcn_rcpf(d));
+                }
                 o[j] = (bf16)y;
             }
             *reinterpret_cast<bf16x8*>(out + row * C + (int64_t)vi * 8) = o;
@@ -55,31 +68,54 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16* __restrict
 //   with t' = t*ft + a - drop, y' = y*fs + b, x' = x*fs + c   (DupUp3D, models/wan_video_vae.py:417-439)
 __global__ __launch_bounds__(256) void dupup3d_add_kernel(const bf16* __restrict__ x, const bf16* __restrict__ main_path,
                                                           bf16* __restrict__ out, int T, int H, int W, int Cin, int Cout,
-                                                          int ft, int fs, int drop) {
-    const int To = T * ft - drop, Ho = H * fs, Wo = W * fs;
+                                                          int ft, int fs, int drop, int rep_shift) {
+    // grid: x over (output column, 8-channel vector), y = output row, z = output frame: no division reaches 64 bits, none is per element
+    const int Ho = H * fs, Wo = W * fs;
     const int factor = ft * fs * fs;
     const int repeats = Cout * factor / Cin;
     const int cvec = Cout >> 3;
-    const int64_t total = (int64_t)To * Ho * Wo * cvec;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % cvec);
-        int64_t pix = i / cvec;
-        const int xo = (int)(pix % Wo); pix /= Wo;
-        const int yo = (int)(pix % Ho);
-        const int to = (int)(pix / Ho) + drop;
-        const int t = to / ft, a = to % ft, y = yo / fs, b = yo % fs, xx = xo / fs, c = xo % fs;
-        const int sub = a * fs * fs + b * fs + c;
-        const bf16* src = x + (((int64_t)t * H + y) * W + xx) * Cin;
-        const bf16x8 m = *reinterpret_cast<const bf16x8*>(main_path + i * 8);
-        bf16x8 o;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Wo * cvec) return;
+    const int xo = idx / cvec, cv = idx - xo * cvec;
+    const int yo = blockIdx.y, to = (int)blockIdx.z + drop;
+    const int t = to / ft, a = to - t * ft, y = yo / fs, b = yo - y * fs, xx = xo / fs, c = xo - xx * fs;
+    const int sub = a * fs * fs + b * fs + c;
+    const bf16* src = x + (((int64_t)t * H + y) * W + xx) * Cin;
+    const int64_t i = (((int64_t)blockIdx.z * Ho + yo) * Wo + xo) * cvec + cv;
+    const bf16x8 m = *reinterpret_cast<const bf16x8*>(main_path + i * 8);
+    bf16x8 o;
+    const int stride = factor / repeats;      // repeats | factor (every DupUp3D of the VAE38 decoder): source channel = oc * stride + sub / repeats
+    if (stride * repeats == factor && stride <= 4 && (Cin & 7) == 0) {
+        // the 8 source channels of this vector sit in `stride` consecutive 16-byte vectors: vector loads instead of 8 two-byte gathers
+        bf16 sv[32];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < stride) *reinterpret_cast<bf16x8*>(sv + 8 * q) = *reinterpret_cast<const bf16x8*>(src + (cv * stride + q) * 8);
+        const int off = sub / repeats;
+        // element j takes sv[j * stride + off]: written with compile-time indices (a run-time index would push sv into scratch memory)
+        auto pick = [&](auto stride_c) {
+            constexpr int S = decltype(stride_c)::value;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (float)sv[j * S];
+#pragma unroll
+                for (int k = 1; k < S; ++k) v = off == k ? (float)sv[j * S + k] : v;
+                o[j] = (bf16)((float)m[j] + v);
+            }
+        };
+        if (stride == 1) pick(std::integral_constant<int, 1>{});
+        else if (stride == 2) pick(std::integral_constant<int, 2>{});
+        else if (stride == 3) pick(std::integral_constant<int, 3>{});
+        else pick(std::integral_constant<int, 4>{});
+    } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int oc = cv * 8 + j;
-            const float s = (float)src[(oc * factor + sub) / repeats];
-            o[j] = (bf16)((float)m[j] + s);
+            const int num = (cv * 8 + j) * factor + sub;
+            const float s1 = (float)src[rep_shift >= 0 ? (num >> rep_shift) : (num / repeats)];
+            o[j] = (bf16)((float)m[j] + s1);
         }
-        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
     }
+    *reinterpret_cast<bf16x8*>(out + i * 8) = o;
 }
 
 // one 256-thread block per row: probs = softmax(scores*scale) rounded to bf16
@@ -272,10 +308,14 @@ int fg_dupup3d_add_bf16(const void* x, const void* main_path, void* out, int T, 
     FG_CHECK_ARG((Cout * ft * fs * fs) % Cin == 0, "fg_dupup3d_add_bf16: out_channels*factor must be divisible by in_channels");
     FG_CHECK_ARG(FG_ALIGNED16(main_path) && FG_ALIGNED16(out), "fg_dupup3d_add_bf16: misaligned pointer");
     const int drop = first_chunk ? ft - 1 : 0;
-    const int64_t total = (int64_t)(T * ft - drop) * H * fs * W * fs * (Cout / 8);
-    if (total <= 0) return FG_OK;
-    hipLaunchKernelGGL(dupup3d_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                       (const bf16*)main_path, (bf16*)out, T, H, W, Cin, Cout, ft, fs, drop);
+    const int To = T * ft - drop, Ho = H * fs, Wo = W * fs, repeats = Cout * ft * fs * fs / Cin;
+    if (To <= 0) return FG_OK;
+    FG_CHECK_ARG(Ho <= 65535 && To <= 65535 && (int64_t)Wo * (Cout / 8) < (1ll << 31), "fg_dupup3d_add_bf16: output too large for the grid");
+    int rep_shift = -1;
+    for (int sft = 0; sft < 16; ++sft)
+        if ((1 << sft) == repeats) rep_shift = sft;
+    hipLaunchKernelGGL(dupup3d_add_kernel, dim3((unsigned)((Wo * (Cout / 8) + 255) / 256), (unsigned)Ho, (unsigned)To), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)x, (const bf16*)main_path, (bf16*)out, T, H, W, Cin, Cout, ft, fs, drop, rep_shift);
     return fg_launch_status("fg_dupup3d_add_bf16");
 }
 
