@@ -228,6 +228,27 @@ def test_gemm_unit_scheduler(hip, M, K, N):
     assert all(wnt is None or torch.equal(g, wnt) for g, wnt in zip(run(), want))
 
 
+def test_gemm_two_streams(hip):
+    """Launches on different streams use different cursor blocks (the library keeps one per (device, stream)) and do not wait on each other:
+    two streams issuing the persistent GEMM concurrently — its workgroups take CUs as they come free, nothing spins — give the single-stream
+    results bit for bit."""
+    shapes = [(4200, 512, 4096), (2700, 3072, 3072), (600, 14336, 3072)]
+    data = [(dev(seeded((1, m, k), 171 + i)), dev(seeded((n, k), 181 + i, scale=0.05)), dev(seeded((n,), 191 + i, scale=0.2))) for i, (m, k, n) in enumerate(shapes)]
+    want = [hip.gemm_epilogue(x, w, b) for x, w, b in data]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for rep in range(6):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                x, w, b = data[(rep + si) % len(data)]
+                got[si].append(((rep + si) % len(data), hip.gemm_epilogue(x, w, b)))
+    torch.cuda.synchronize()
+    for si in range(2):
+        for idx, y in got[si]:
+            assert torch.equal(y, want[idx]), f"stream {si}, shape {shapes[idx]}"
+
+
 @pytest.mark.parametrize("M,K,N", [(700, 3072, 768),        # 9 tiles: 64-column pieces (second body); 24 k-steps of 128 e4m3
                                    (4200, 1024, 4096),      # 272 tiles: a full round + cut tail, ragged last rows, 8 k-steps
                                    (600, 14336, 3072)])     # ffn.2's reduction: 112 k-steps, left-over tiles as k-range pieces + reduce kernel
