@@ -166,7 +166,12 @@ int fg_act_bf16(const void* x, void* out, int64_t n, int kind, fg_stream_t strea
  * workspace (optional, may be NULL/0): fg_attn_workspace_bytes(B,Nq,Nkv,H) bytes of scratch let the launcher cut
  * the tail q-blocks (or, for short query ranges such as a 1/8 token shard, every q-block) into KV ranges that are
  * merged by a second small kernel, so that the workgroup count fills the 256 CUs evenly; results are the same up
- * to fp32 summation order.  K/V of one batch element must span < 4 GiB. */
+ * to fp32 summation order.  K/V of one batch element must span < 4 GiB.
+ * scale: any positive value.  Self-attention shapes (Nkv > 1024) run a hand-scheduled 4-wave kernel in one of two forms with the same
+ * result contract: when scale * log2(e) is a power of two (to 1e-6: pass 2^e / log2(e)) Q^T is pre-multiplied by it — exact in bf16 — and
+ * the exponent needs no per-score multiply; for any other scale (e.g. 1/sqrt(128)) the scores of the exact operands are scaled in fp32.
+ * A caller that wants the faster form for 1/sqrt(d) folds the factor 2^-e / sqrt(d) * log2(e) into q itself (wan_video_dit.py does,
+ * through q's RoPE table). */
 int64_t fg_attn_workspace_bytes(int B, int64_t Nq, int64_t Nkv, int H);
 /* Diagnostic: the decomposition the launcher picks for this shape and workspace size: the last R q-blocks of every
  * (batch, head) are cut into S KV ranges (R == 0: no split). */
